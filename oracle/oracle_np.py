@@ -1,0 +1,632 @@
+"""
+TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+
+numpy "definition" oracle for the Scythe.jl spectral-transform time-stepping hot path.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+It restates, as dense linear operators (O(N^2) on purpose - it is a definition, not an
+implementation), the algorithm that the reference obtains from the external, un-vendored
+package Springsteel.jl (Project.toml:20, unpinned) at these call sites:
+
+  spectralTransform!  (forward, physical -> B coefficients)   src/semiimplicit.jl:135,734
+  splineTransform!    (B -> A banded SPD solve with patch BCs) src/semiimplicit.jl:237,285
+  tileTransform!      (A -> physical value + derivatives)      src/semiimplicit.jl:241,305
+  Chebyshev column ops CB/CA/CI/CIx/CIxx/CIInt                src/semiimplicit.jl:569-596,
+                                                              src/shallowWaterModels.jl:423-504
+and the in-tree step structure (src/semiimplicit.jl:301-332, 672-698, 521-597, 768-781) plus
+equation sets (src/testModels.jl:1-98, src/shallowWaterModels.jl:1-233, 346-511).
+
+Parity status:
+  * R-grid cubic-B-spline + AB3 pipeline: PINNED by the reference's notebook known-answer
+    (notebooks/LinearAdvection_example.ipynb cells 2, 7, 9) -> tests/golden/linear_advection_kat.json.
+  * Fourier / Chebyshev / RL / RZ / RLZ layouts / semi-implicit solve: PARITY UNPINNED (no reference
+    fixture exists, Springsteel source and Julia are absent); these follow SURVEY.md 8(c)'s spec.
+"""
+import numpy as np
+
+# ----------------------------------------------------------------------------- constants
+SQRT35 = np.sqrt(3.0 / 5.0)
+GAUSS_OFF = np.array([-SQRT35 / 2.0, 0.0, SQRT35 / 2.0])   # mish offsets inside a unit cell, centred
+QUAD_W = np.array([8.0, 5.0, 8.0]) / 21.0                  # ratio 8:5:8 pinned by the notebook KAT
+MUBAR = 3
+
+BC_RANK = {"R0": 0, "R1T0": 1, "R1T1": 1, "R1T2": 1, "R2T10": 2, "R2T20": 2, "R3": 3}
+R1_COEF = {"R1T0": (-4.0, -1.0), "R1T1": (0.0, 1.0), "R1T2": (2.0, -1.0)}
+
+
+# ----------------------------------------------------------------------------- cubic B-spline
+def bspline(delta, d):
+    """d-th derivative (w.r.t. delta) of the cardinal cubic B-spline, vectorised."""
+    delta = np.asarray(delta, dtype=np.float64)
+    z = np.abs(delta)
+    s = np.where(delta > 0, 1.0, -1.0)
+    p = 2.0 - z
+    q = np.maximum(1.0 - z, 0.0)
+    if d == 0:
+        out = p ** 3 / 6.0 - 4.0 * q ** 3 / 6.0
+    elif d == 1:
+        out = -s * (p * p / 2.0 - 2.0 * q * q)
+    elif d == 2:
+        out = p - 4.0 * q
+    else:
+        out = s * np.where(z < 1.0, 3.0, -1.0)
+    return np.where(z < 2.0, out, 0.0)
+
+
+def gamma_matrix(nc, bcl, bcr):
+    """BC projection Gamma (nfree x bDim): full coefficients a = Gamma^T a_free."""
+    bdim = nc + 3
+    if bcl == "PERIODIC" or bcr == "PERIODIC":
+        assert bcl == bcr == "PERIODIC"
+        G = np.zeros((nc, bdim))
+        for m in range(-1, nc + 2):
+            G[m % nc, m + 1] = 1.0
+        return G
+    rl, rr = BC_RANK[bcl], BC_RANK[bcr]
+    nfree = bdim - rl - rr
+    G = np.zeros((nfree, bdim))
+    for j in range(nfree):
+        G[j, rl + j] = 1.0
+    # left boundary: dependent coefficients expressed through the first free ones
+    if bcl in R1_COEF:
+        al, be = R1_COEF[bcl]
+        G[0, 0] += al
+        G[1, 0] += be
+    elif bcl == "R2T10":
+        G[0, 0] += 1.0
+        G[0, 1] += -0.5
+    elif bcl == "R2T20":
+        G[0, 0] += -1.0
+    # right boundary, mirrored
+    if bcr in R1_COEF:
+        al, be = R1_COEF[bcr]
+        G[nfree - 1, bdim - 1] += al
+        G[nfree - 2, bdim - 1] += be
+    elif bcr == "R2T10":
+        G[nfree - 1, bdim - 1] += 1.0
+        G[nfree - 1, bdim - 2] += -0.5
+    elif bcr == "R2T20":
+        G[nfree - 1, bdim - 1] += -1.0
+    return G
+
+
+class Spline1D:
+    """Cubic B-spline on [xmin, xmax] with nc cells; nodes m = -1..nc+1 (array index m+1)."""
+
+    def __init__(self, xmin, xmax, nc, l_q=2.0, bcl="R0", bcr="R0"):
+        self.xmin, self.xmax, self.nc = float(xmin), float(xmax), int(nc)
+        self.DX = (self.xmax - self.xmin) / self.nc
+        self.bdim = self.nc + 3
+        self.l_q, self.bcl, self.bcr = l_q, bcl, bcr
+        self.mish = mish_points(self.xmin, self.DX, 0, self.nc)
+        self.W = np.tile(self.DX * QUAD_W, self.nc)
+        ph0 = self.basis(self.mish, 0)
+        ph3 = self.basis(self.mish, 3)
+        eps_q = (l_q * self.DX / (2.0 * np.pi)) ** 6
+        self.P = ph0.T @ (self.W[:, None] * ph0) + eps_q * (ph3.T @ (self.W[:, None] * ph3))
+        self.G = gamma_matrix(self.nc, bcl, bcr)
+        self.PQ = self.G @ self.P @ self.G.T
+        self.cho = np.linalg.cholesky(self.PQ)
+
+    def basis(self, x, d):
+        """Phi_d[i, m+1] = d^d/dx^d phi_m(x_i)."""
+        x = np.asarray(x, dtype=np.float64)
+        xm = self.xmin + (np.arange(self.bdim) - 1) * self.DX
+        delta = (x[:, None] - xm[None, :]) / self.DX
+        return bspline(delta, d) / self.DX ** d
+
+    def SB(self, u):           # physical at own mish -> B
+        return self.basis(self.mish, 0).T @ (self.W * u)
+
+    def SA(self, b):           # B -> A (with BCs)
+        y = np.linalg.solve(self.cho, self.G @ b)
+        return self.G.T @ np.linalg.solve(self.cho.T, y)
+
+
+def mish_points(xmin, DX, cell0, ncells):
+    c = np.arange(cell0, cell0 + ncells)
+    return (xmin + DX * (c[:, None] + 0.5 + GAUSS_OFF[None, :])).reshape(-1)
+
+
+# ----------------------------------------------------------------------------- Fourier ring
+class Ring:
+    def __init__(self, L, kmax, offset):
+        self.L, self.kmax, self.offset = int(L), int(kmax), float(offset)
+        self.lam = self.offset + 2.0 * np.pi * np.arange(self.L) / self.L
+        nb = 1 + 2 * self.kmax
+        self.FB = np.zeros((nb, self.L))
+        self.FI = [np.zeros((self.L, nb)) for _ in range(3)]
+        self.FB[0, :] = 1.0 / self.L
+        self.FI[0][:, 0] = 1.0
+        for k in range(1, self.kmax + 1):
+            c, s = np.cos(k * self.lam), np.sin(k * self.lam)
+            self.FB[2 * k - 1] = c / self.L
+            self.FB[2 * k] = -s / self.L
+            self.FI[0][:, 2 * k - 1] = 2.0 * c
+            self.FI[0][:, 2 * k] = -2.0 * s
+            self.FI[1][:, 2 * k - 1] = -2.0 * k * s
+            self.FI[1][:, 2 * k] = -2.0 * k * c
+            self.FI[2][:, 2 * k - 1] = -2.0 * k * k * c
+            self.FI[2][:, 2 * k] = 2.0 * k * k * s
+
+
+# ----------------------------------------------------------------------------- Chebyshev column
+class Cheb:
+    """Chebyshev-Gauss-Lobatto column, index 0 = bottom (z = zmin, x = +1)."""
+
+    def __init__(self, zmin, zmax, N, bdim=None, bcb="R0", bct="R0"):
+        self.zmin, self.zmax, self.N = float(zmin), float(zmax), int(N)
+        self.bdim = int(bdim) if bdim else default_bzdim(N)
+        N = self.N
+        n = np.arange(N)
+        self.x = np.cos(n * np.pi / (N - 1))
+        self.z = self.x * (-0.5 * (self.zmax - self.zmin)) + 0.5 * (self.zmin + self.zmax)
+        w = np.full(N, 2.0)
+        w[0] = w[-1] = 1.0
+        self.T = w[None, :] * np.cos(np.outer(n, n) * np.pi / (N - 1))   # dct_matrix: a -> values
+        self.CBm = (self.T / (2.0 * (N - 1)))[: self.bdim, :]            # values -> b (truncated)
+        Lz = self.zmax - self.zmin
+        # coefficient-space derivative (a -> ax), DCT-I normalisation u = a0 + 2 sum a_k T_k + a_{N-1} T_{N-1}
+        Dc = np.zeros((N, N))
+        for j in range(N):
+            a = np.zeros(N)
+            a[j] = 1.0
+            ax = np.zeros(N + 2)
+            for k in range(N - 1, 0, -1):
+                ck = a[k] if k == N - 1 else 2.0 * a[k]
+                ax[k - 1] = ax[k + 1] + k * ck
+            Dc[:, j] = ax[:N]
+        self.Dc = Dc * (-2.0 / Lz)
+        # coefficient-space indefinite integral (zero at the bottom)
+        Ic = np.zeros((N, N))
+        for j in range(N):
+            a = np.zeros(N)
+            a[j] = 1.0
+            ai = np.zeros(N)
+            for k in range(1, N - 1):
+                up = a[k + 1] if k + 1 < N - 1 else 0.5 * a[k + 1]
+                ai[k] = (a[k - 1] - up) / (2.0 * k)
+            ai[N - 1] = a[N - 2] / (N - 1)
+            ai *= (-0.5 * Lz)
+            ai[0] = -(2.0 * ai[1:N - 1].sum() + ai[N - 1])
+            Ic[:, j] = ai
+        self.Ic = Ic
+        # BC projection in coefficient space (orthogonal projection onto the constraint null space)
+        rows = []
+        for bc, row in ((bcb, 0), (bct, N - 1)):
+            if bc == "R0":
+                continue
+            if bc == "R1T0":
+                rows.append(self.T[row, :])
+            elif bc == "R1T1":
+                rows.append((self.T @ self.Dc)[row, :])
+            elif bc == "R1T2":
+                rows.append((self.T @ self.Dc @ self.Dc)[row, :])
+            else:
+                raise ValueError("unsupported vertical BC " + bc)
+        pad = np.zeros((N, self.bdim))
+        pad[: self.bdim, : self.bdim] = np.eye(self.bdim)
+        if rows:
+            C = np.array(rows)
+            proj = np.eye(N) - C.T @ np.linalg.solve(C @ C.T, C)
+        else:
+            proj = np.eye(N)
+        self.CAm = proj @ pad                       # b -> a
+        self.M = [self.T @ self.CAm,                # b -> values
+                  self.T @ self.Dc @ self.CAm,      # b -> d/dz
+                  self.T @ self.Dc @ self.Dc @ self.CAm]
+        self.Mint = self.T @ self.Ic @ self.CAm     # b -> integral from the bottom
+
+    # dense collocation matrices used by calc_Helmholtz_semiimplicit_matrix (src/semiimplicit.jl:772-775)
+    def dct_matrix(self):
+        return self.T
+
+    def dct_1st_derivative(self):
+        return self.T @ self.Dc
+
+    def dct_2nd_derivative(self):
+        return self.T @ self.Dc @ self.Dc
+
+
+def default_bzdim(zdim):
+    return int(min(zdim, np.floor((2 * zdim - 1) / 3) + 1))
+
+
+# ----------------------------------------------------------------------------- grid
+DERIV_SLOTS = {"R": ["u", "r", "rr"], "RZ": ["u", "r", "rr", "z", "zz"],
+               "RL": ["u", "r", "rr", "l", "ll"], "RLZ": ["u", "r", "rr", "l", "ll", "z", "zz"]}
+
+
+class Grid:
+    """Patch description + tile-level transforms. Tiles are (cell0, ncells) sub-ranges of the patch."""
+
+    def __init__(self, geometry, xmin, xmax, num_cells, vars, BCL=None, BCR=None, l_q=2.0,
+                 zmin=0.0, zmax=0.0, zDim=0, b_zDim=None, BCB=None, BCT=None,
+                 ring_L=None, BCL_k0=None):
+        self.geometry = geometry
+        self.xmin, self.xmax, self.nc = float(xmin), float(xmax), int(num_cells)
+        self.DX = (self.xmax - self.xmin) / self.nc
+        self.vars = dict(vars)                                   # name -> 1-based index
+        self.names = [n for n, _ in sorted(self.vars.items(), key=lambda kv: kv[1])]
+        self.V = len(self.names)
+        self.l_q = l_q
+        dflt = lambda d, v: (d or {}).get(v, "R0")
+        self.BCL = {v: dflt(BCL, v) for v in self.names}
+        self.BCR = {v: dflt(BCR, v) for v in self.names}
+        self.BCL_k0 = {v: (BCL_k0 or {}).get(v, self.BCL[v]) for v in self.names}
+        self.BCB = {v: dflt(BCB, v) for v in self.names}
+        self.BCT = {v: dflt(BCT, v) for v in self.names}
+        self.has_l = "L" in geometry
+        self.has_z = "Z" in geometry
+        self.rDim = MUBAR * self.nc
+        self.b_rDim = self.nc + 3
+        self.zDim = int(zDim) if self.has_z else 1
+        self.b_zDim = (int(b_zDim) if b_zDim else default_bzdim(self.zDim)) if self.has_z else 1
+        self.zmin, self.zmax = zmin, zmax
+        self.slots = DERIV_SLOTS[geometry]
+        self.D = len(self.slots)
+        # ring table (patch-level, ring index ri = 1..rDim)
+        if self.has_l:
+            ri = np.arange(1, self.rDim + 1)
+            if ring_L is None:                     # native Springsteel layout
+                self.L = 4 + 4 * ri
+                self.kmax = ri.copy()
+                self.off = 0.5 * (2.0 * np.pi / self.L) * (ri - 1)
+            else:                                  # uniform ring table (perf shape)
+                self.L = np.full(self.rDim, int(ring_L))
+                self.kmax = np.minimum(ri, int(ring_L) // 2 - 1)
+                self.off = np.zeros(self.rDim)
+        else:
+            self.L = np.ones(self.rDim, dtype=int)
+            self.kmax = np.zeros(self.rDim, dtype=int)
+            self.off = np.zeros(self.rDim)
+        self.ringstart = np.concatenate([[0], np.cumsum(self.L)])
+        self.kDim = int(self.kmax.max())
+        self.K2 = 1 + 2 * self.kDim
+        self.rings = [Ring(self.L[r], self.kmax[r], self.off[r]) for r in range(self.rDim)]
+        self._spl = {}
+        self._cheb = {}
+
+    # -- helpers
+    def spline(self, bcl, bcr):
+        key = (bcl, bcr)
+        if key not in self._spl:
+            self._spl[key] = Spline1D(self.xmin, self.xmax, self.nc, self.l_q, bcl, bcr)
+        return self._spl[key]
+
+    def cheb(self, v):
+        key = (self.BCB[v], self.BCT[v])
+        if key not in self._cheb:
+            self._cheb[key] = Cheb(self.zmin, self.zmax, self.zDim, self.b_zDim, *key)
+        return self._cheb[key]
+
+    def var_spline(self, v, blk):
+        bcl = self.BCL_k0[v] if blk == 0 else self.BCL[v]
+        return self.spline(bcl, self.BCR[v])
+
+    def tile_rings(self, cell0, ncells):
+        return range(MUBAR * cell0, MUBAR * (cell0 + ncells))
+
+    def tile_npoints(self, cell0, ncells):
+        rr = self.tile_rings(cell0, ncells)
+        return int((self.ringstart[rr[-1] + 1] - self.ringstart[rr[0]]) * self.zDim)
+
+    def tile_K2(self, cell0, ncells):
+        rr = self.tile_rings(cell0, ncells)
+        return 1 + 2 * int(self.kmax[rr[0]:rr[-1] + 1].max())
+
+    def S_patch(self):
+        return self.b_zDim * self.K2 * self.b_rDim
+
+    def gridpoints(self, cell0=0, ncells=None):
+        ncells = self.nc if ncells is None else ncells
+        r = mish_points(self.xmin, self.DX, cell0, ncells)
+        cols = []
+        zc = self.cheb(self.names[0]).z if self.has_z else np.zeros(1)
+        for i, ring in enumerate(self.tile_rings(cell0, ncells)):
+            for l in range(self.L[ring]):
+                for z in range(self.zDim):
+                    row = [r[i]]
+                    if self.has_l:
+                        row.append(self.rings[ring].lam[l])
+                    if self.has_z:
+                        row.append(zc[z])
+                    cols.append(row)
+        out = np.array(cols)
+        return out[:, 0] if out.shape[1] == 1 else out
+
+    # -- forward: tile physical values [N_t, V] -> tile B coefficients, reference tile layout
+    #    spectral[(zm*K2_t + blk)*(ncells+3) + j, v]
+    def forward(self, values, cell0=0, ncells=None):
+        ncells = self.nc if ncells is None else ncells
+        rr = list(self.tile_rings(cell0, ncells))
+        K2t = self.tile_K2(cell0, ncells)
+        nbt = ncells + 3
+        tile_spl = Spline1D(self.xmin + cell0 * self.DX, self.xmin + (cell0 + ncells) * self.DX, ncells)
+        ph0 = tile_spl.basis(tile_spl.mish, 0)                 # [3*ncells, nbt]
+        # quadrature weights use the patch DX (identical up to rounding)
+        W = np.tile(self.DX * QUAD_W, ncells)
+        out = np.zeros((self.b_zDim * K2t * nbt, self.V))
+        base = self.ringstart[rr[0]]
+        for vi, v in enumerate(self.names):
+            ch = self.cheb(v) if self.has_z else None
+            F = np.zeros((len(rr), self.b_zDim, K2t))           # ring, zmode, block
+            for i, ring in enumerate(rr):
+                L = self.L[ring]
+                p0 = (self.ringstart[ring] - base) * self.zDim
+                u = values[p0:p0 + L * self.zDim, vi].reshape(L, self.zDim)   # [lambda, z]
+                bz = (ch.CBm @ u.T) if self.has_z else u.T                    # [zm, lambda]
+                c = bz @ self.rings[ring].FB.T                                # [zm, blocks of ring]
+                F[i, :, :c.shape[1]] = c
+            for zm in range(self.b_zDim):
+                for blk in range(K2t):
+                    b = ph0.T @ (W * F[:, zm, blk])
+                    o = (zm * K2t + blk) * nbt
+                    out[o:o + nbt, vi] = b
+        return out
+
+    # -- the shared-array sum protocol of src/semiimplicit.jl:320-329, 279-282
+    def add_tile_to_shared(self, shared, btile, cell0, ncells, last):
+        K2t = self.tile_K2(cell0, ncells)
+        nbt = ncells + 3
+        for zm in range(self.b_zDim):
+            for blk in range(K2t):
+                o = (zm * K2t + blk) * nbt
+                p = (zm * self.K2 + blk) * self.b_rDim + cell0
+                shared[p:p + nbt, :] += btile[o:o + nbt, :]
+        return shared
+
+    # -- B -> A for the whole patch (reference layout [S_patch, V])
+    def spline_transform(self, shared):
+        A = np.zeros_like(shared)
+        for vi, v in enumerate(self.names):
+            for zm in range(self.b_zDim):
+                for blk in range(self.K2):
+                    p = (zm * self.K2 + blk) * self.b_rDim
+                    A[p:p + self.b_rDim, vi] = self.var_spline(v, blk).SA(shared[p:p + self.b_rDim, vi])
+        return A
+
+    # -- inverse: patch A -> tile physical [N_t, V, D]
+    def inverse(self, A, cell0=0, ncells=None):
+        ncells = self.nc if ncells is None else ncells
+        rr = list(self.tile_rings(cell0, ncells))
+        Nt = self.tile_npoints(cell0, ncells)
+        phys = np.zeros((Nt, self.V, self.D))
+        r = mish_points(self.xmin, self.DX, cell0, ncells)
+        spl = self.spline("R0", "R0")
+        PH = [spl.basis(r, d) for d in range(3)]               # [rings, b_rDim]
+        base = self.ringstart[rr[0]]
+        sl = {s: i for i, s in enumerate(self.slots)}
+        for vi, v in enumerate(self.names):
+            ch = self.cheb(v) if self.has_z else None
+            Av = A[:, vi].reshape(self.b_zDim, self.K2, self.b_rDim)
+            for i, ring in enumerate(rr):
+                rg = self.rings[ring]
+                nb = 1 + 2 * rg.kmax
+                L = rg.L
+                p0 = (self.ringstart[ring] - base) * self.zDim
+                sel = slice(p0, p0 + L * self.zDim)
+                for d, name in enumerate(["u", "r", "rr"]):
+                    coef = Av[:, :nb, :] @ PH[d][i]                          # [zm, blocks]
+                    lam_sets = [(0, name)] if d > 0 else [(0, "u"), (1, "l"), (2, "ll")]
+                    for ld, sname in lam_sets:
+                        if sname not in sl:
+                            continue
+                        f = coef @ rg.FI[ld].T                               # [zm, lambda]
+                        if self.has_z:
+                            phys[sel, vi, sl[sname]] = (ch.M[0] @ f).T.reshape(-1)
+                            if sname == "u":
+                                phys[sel, vi, sl["z"]] = (ch.M[1] @ f).T.reshape(-1)
+                                phys[sel, vi, sl["zz"]] = (ch.M[2] @ f).T.reshape(-1)
+                        else:
+                            phys[sel, vi, sl[sname]] = f.T.reshape(-1)
+        return phys
+
+
+# ----------------------------------------------------------------------------- time stepping
+def explicit_timestep(t, ts, u, e_n, e_nm1, e_nm2):
+    """Euler / AB2 / AB3 (src/semiimplicit.jl:672-698). Returns (u_np1, e_nm1', e_nm2')."""
+    if t == 1:
+        return u + ts * e_n, e_n.copy(), e_nm2
+    if t == 2:
+        return u + (0.5 * ts) * ((3.0 * e_n) - e_nm1), e_n.copy(), e_nm1.copy()
+    return u + ((ts / 12.0) * ((23.0 * e_n) - (16.0 * e_nm1) + (5.0 * e_nm2))), e_n.copy(), e_nm1.copy()
+
+
+def helmholtz_matrix(ch, pxi_bar, tau):
+    """calc_Helmholtz_semiimplicit_matrix (src/semiimplicit.jl:768-781)."""
+    c = tau * tau * pxi_bar
+    dct, dct2 = ch.dct_matrix(), ch.dct_2nd_derivative()
+    h = c * dct2 - dct
+    return np.vstack([c * dct[0:1, :], c * dct[-1:, :], h[1:-1, :]])
+
+
+def tendency(grid, eq, par, phys, pts, col_ops=None):
+    """Pointwise tendencies of the in-scope equation sets. phys [N,V,D]; returns (expdot [N,V], impdot [N,V] or None, phys)
+    (phys is returned because the shallow-water sets overwrite the diagnostic w in slot 1)."""
+    N = phys.shape[0]
+    E = np.zeros((N, grid.V))
+    I = None
+    P = lambda v, s: phys[:, v - 1, grid.slots.index(s)]
+    if eq == "LinearAdvection1D":                       # src/testModels.jl:1-20
+        E[:, 0] = -(par["c_0"] * P(1, "r")) + (par["K"] * P(1, "rr"))
+    elif eq == "LinearAdvectionRZ":                     # src/testModels.jl:22-45
+        r = pts[:, 0]
+        E[:, 0] = (-P(2, "u") * P(1, "r")) + (-P(4, "u") * P(1, "z")) + \
+                  (par["K"] * ((P(1, "r") / r) + P(1, "rr") + P(1, "zz")))
+    elif eq in ("LinearAdvectionRL", "LinearAdvectionRLZ"):   # src/testModels.jl:47-98
+        r = pts[:, 0]
+        E[:, 0] = (-P(2, "u") * P(1, "r")) - (P(3, "u") * (P(1, "l") / r))
+        if par["K"] > 0.0 or eq == "LinearAdvectionRLZ":
+            E[:, 0] += par["K"] * ((P(1, "r") / r) + P(1, "rr") + (P(1, "ll") / (r * r)))
+    elif eq in ("Oneway_ShallowWater_Slab", "Twoway_ShallowWater_Slab"):   # src/shallowWaterModels.jl:1-233
+        r = pts[:, 0]
+        g, K, Cd, Hfree, Hb, f = (par[k] for k in ("g", "K", "Cd", "Hfree", "Hb", "f"))
+        h, hr, hl = P(1, "u"), P(1, "r"), P(1, "l")
+        ug, ugr, ugl = P(2, "u"), P(2, "r"), P(2, "l")
+        vg, vgr, vgl = P(3, "u"), P(3, "r"), P(3, "l")
+        ub, ubr, ubrr, ubl, ubll = P(4, "u"), P(4, "r"), P(4, "rr"), P(4, "l"), P(4, "ll")
+        vb, vbr, vbrr, vbl, vbll = P(5, "u"), P(5, "r"), P(5, "rr"), P(5, "l"), P(5, "ll")
+        U = 0.78 * np.sqrt((ub * ub) + (vb * vb))
+        w = -Hb * ((ub / r) + ubr + (vbl / r))
+        phys[:, 5, 0] = w
+        w_ = 0.5 * np.abs(w) - w
+        E[:, 0] = ((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)))
+        if eq.startswith("Twoway"):
+            E[:, 0] += -(Hfree + h) * w * par["S1"]
+        E[:, 1] = ((-vg * ugl / r) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg / r)))
+        E[:, 2] = ((-vg * vgl / r) + (-ug * vgr)) + (-g * (hl / r)) + (-ug * (f + (vg / r)))
+        E[:, 3] = ((-vb * ubl / r) + (-ub * ubr)) + (-g * hr) + (vb * (f + (vb / r))) + (-(Cd * U * ub / Hb)) \
+            + (w_ * (ug - ub) / Hb) \
+            + (K * ((ubr / r) + ubrr - (ub / (r * r)) + (ubll / (r * r)) - (2.0 * vbl / (r * r))))
+        E[:, 4] = ((-vb * vbl / r) + (-ub * vbr)) + (-g * (hl / r)) + (-ub * (f + (vb / r))) + (-(Cd * U * vb / Hb)) \
+            + (w_ * (vg - vb) / Hb) \
+            + (K * ((vbr / r) + vbrr - (vb / (r * r)) + (vbll / (r * r)) + (2.0 * ubl / (r * r))))
+    elif eq == "Oneway_ShallowWater_HeightResolvedBL":   # src/shallowWaterModels.jl:346-511
+        nz = grid.zDim
+        ch = grid.cheb("h")                              # "h" carries no vertical BC (ref :422-425)
+        Mint = ch.Mint @ ch.CBm
+        Mdz = ch.M[1] @ ch.CBm
+        colv = lambda a: a.reshape(-1, nz)
+        r, lam, z = colv(pts[:, 0]), colv(pts[:, 1]), colv(pts[:, 2])
+        g, Kh, Cd0, Hfree, f, Um, Vm = (par[k] for k in ("g", "Kh", "Cd", "Hfree", "f", "Um", "Vm"))
+        Q = lambda v, s: colv(P(v, s))
+        h, hr, hl = Q(1, "u"), Q(1, "r"), Q(1, "l")
+        ug, ugr, ugl = Q(2, "u"), Q(2, "r"), Q(2, "l")
+        vg, vgr, vgl = Q(3, "u"), Q(3, "r"), Q(3, "l")
+        ub, ubr, ubrr, ubl, ubll, ubz = (Q(4, s) for s in ("u", "r", "rr", "l", "ll", "z"))
+        vb, vbr, vbrr, vbl, vbll, vbz = (Q(5, s) for s in ("u", "r", "rr", "l", "ll", "z"))
+        S = np.sqrt((ubz * ubz) + (vbz * vbz))
+        l = 1.0 / ((1.0 / (0.4 * z)) + (1.0 / 80.0))
+        Kv = (l ** 2) * S
+        wb = (-((ub / r) + ubr + (vbl / r))) @ Mint.T
+        phys[:, 5, 0] = wb.reshape(-1)
+        sfcu = (Um * np.cos(lam[:, 0])) + (Vm * np.sin(lam[:, 0]))
+        sfcv = (Vm * np.cos(lam[:, 0])) - (Um * np.sin(lam[:, 0]))
+        u10, v10 = ub[:, 1] + sfcu, vb[:, 1] + sfcv
+        U10 = np.sqrt(u10 ** 2 + v10 ** 2)
+        Cd = np.where(U10 < 5.2, 1.0e-3, np.where(U10 < 33.6, 4.4e-4 * U10 ** 0.5, Cd0))
+        fu = Kv * ubz
+        fu[:, 0] = Cd * U10 * u10
+        fv = Kv * vbz
+        fv[:, 0] = Cd * U10 * v10
+        VDu, VDv = fu @ Mdz.T, fv @ Mdz.T
+        E4 = ((-vb * ubl / r) + (-ub * ubr) + (-wb * ubz)) + (-g * hr) + (vb * (f + (vb / r))) + VDu \
+            + (Kh * ((ubr / r) + ubrr - (ub / (r * r)) + (ubll / (r * r)) - (2.0 * vbl / (r * r))))
+        E5 = ((-vb * vbl / r) + (-ub * vbr) + (-wb * vbz)) + (-g * (hl / r)) + (-ub * (f + (vb / r))) + VDv \
+            + (Kh * ((vbr / r) + vbrr - (vb / (r * r)) + (vbll / (r * r)) + (2.0 * ubl / (r * r))))
+        E[:, 0] = (((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)))).reshape(-1)
+        E[:, 1] = (((-vg * ugl / r) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg / r)))).reshape(-1)
+        E[:, 2] = (((-vg * vgl / r) + (-ug * vgr)) + (-g * (hl / r)) + (-ug * (f + (vg / r)))).reshape(-1)
+        E[:, 3] = E4.reshape(-1)
+        E[:, 4] = E5.reshape(-1)
+    elif eq == "LinearAcousticRZ":
+        # Synthetic RZ vehicle for semiimplicit_adjustment (config 3). NOT a reference equation set: it keeps
+        # Euler_test's variable layout (s, xi, mu, u, w) and its two implicit terms (src/testModels.jl:188-189,
+        # 204-205) but linearises the pressure-gradient force so no moist thermodynamics is needed.
+        K, pxi = par["K"], par["Pxi_bar"]
+        u, w = P(4, "u"), P(5, "u")
+        adv = lambda v: (-u * P(v, "r")) + (-w * P(v, "z"))
+        dif = lambda v: K * (P(v, "rr") + P(v, "zz"))
+        I = np.zeros((N, grid.V))
+        E[:, 0] = adv(1) + dif(1)
+        E[:, 1] = adv(2) - P(4, "r") - P(5, "z")
+        I[:, 1] = -P(5, "z")
+        E[:, 2] = adv(3) + dif(3)
+        E[:, 3] = adv(4) + (-(pxi * P(2, "r"))) + dif(4)
+        E[:, 4] = adv(5) + (-(pxi * P(2, "z"))) + dif(5)
+        I[:, 4] = -(pxi * P(2, "z"))
+    else:
+        raise ValueError("equation set not in scope: " + eq)
+    return E, I, phys
+
+
+class Model:
+    """One patch split into radial tiles, stepped with the reference's per-step protocol
+    (src/semiimplicit.jl:258-332). Pure numpy; small cases only."""
+
+    def __init__(self, grid, equation_set, ts, params, tiles=None, semiimplicit=False, pxi_bar=0.0):
+        self.g, self.eq, self.ts, self.par = grid, equation_set, float(ts), dict(params)
+        self.tiles = tiles or [(0, grid.nc)]
+        self.semi, self.pxi = semiimplicit, pxi_bar
+        self.hist = [dict(e1=None, e2=None, i1=None, i2=None) for _ in self.tiles]
+        self.A = None
+        self.t = 0
+
+    def set_initial(self, values_patch):
+        """values_patch [N_patch, V]: initialize_model + first splineTransform! (:134-136, :233-237)."""
+        shared = np.zeros((self.g.S_patch(), self.g.V))
+        self._sum_tiles(shared, lambda c0, n: self._tile_slice(values_patch, c0, n))
+        self.A = self.g.spline_transform(shared)
+
+    def _tile_slice(self, arr, c0, n):
+        g = self.g
+        p0 = g.ringstart[MUBAR * c0] * g.zDim
+        return arr[p0:p0 + g.tile_npoints(c0, n)]
+
+    def _sum_tiles(self, shared, fn):
+        for i, (c0, n) in enumerate(self.tiles):
+            b = self.g.forward(fn(c0, n), c0, n)
+            self.g.add_tile_to_shared(shared, b, c0, n, i == len(self.tiles) - 1)
+
+    def physical(self):
+        return np.concatenate([self.g.inverse(self.A, c0, n) for c0, n in self.tiles], axis=0)
+
+    def step(self):
+        self.t += 1
+        t, g = self.t, self.g
+        shared = np.zeros((g.S_patch(), g.V))
+        for i, (c0, n) in enumerate(self.tiles):
+            phys = g.inverse(self.A, c0, n)                                  # tileTransform!
+            pts = g.gridpoints(c0, n)
+            pts = pts.reshape(len(pts), -1)
+            E, I, phys = tendency(g, self.eq, self.par, phys, pts)
+            hs = self.hist[i]
+            if t == 1:
+                hs["e1"] = np.zeros_like(E)
+                hs["e2"] = np.zeros_like(E)
+            unp1, hs["e1"], hs["e2"] = explicit_timestep(t, self.ts, phys[:, :, 0], E, hs["e1"], hs["e2"])
+            if self.semi:
+                unp1 = self._semiimplicit(i, t, unp1, I)
+            b = g.forward(unp1, c0, n)                                       # calcTendency
+            g.add_tile_to_shared(shared, b, c0, n, i == len(self.tiles) - 1)
+        self.A = g.spline_transform(shared)                                  # splineTransform!
+
+    def _semiimplicit(self, i, t, unp1, impdot):
+        """semiimplicit_adjustment (src/semiimplicit.jl:521-597), all columns of tile i at once."""
+        g, ts, hs = self.g, self.ts, self.hist[i]
+        nz = g.zDim
+        wi, xi = g.vars["w"] - 1, g.vars["xi"] - 1
+        I_n = impdot
+        if t == 1:
+            hs["i1"] = np.zeros_like(I_n)
+            hs["i2"] = np.zeros_like(I_n)
+        I1, I2 = hs["i1"], hs["i2"]
+        out = unp1.copy()
+        star = {}
+        for v in (wi, xi):
+            x = unp1[:, v]
+            if t == 1:
+                tau = 0.5 * ts
+                x = x - (ts * I_n[:, v]) + (ts * 0.5 * I_n[:, v])
+            elif t == 2:
+                tau = 1.25 * ts
+                x = x - (0.5 * ts) * ((3.0 * I_n[:, v]) - I1[:, v]) - (ts * I_n[:, v]) + (ts * 0.75 * I1[:, v])
+            else:
+                tau = 1.25 * ts
+                x = x - ((ts / 12.0) * ((23.0 * I_n[:, v]) - (16.0 * I1[:, v]) + (5.0 * I2[:, v]))) \
+                    - (ts * I_n[:, v]) + (ts * 0.75 * I1[:, v])
+            star[v] = x.reshape(-1, nz)
+        hs["i2"], hs["i1"] = I1.copy(), I_n.copy()
+        chx, chw = g.cheb(g.names[xi]), g.cheb(g.names[wi])
+        bxi = star[xi] @ chx.CBm.T
+        xi_star = bxi @ chx.M[0].T
+        xi_star_z = tau * self.pxi * (bxi @ chx.M[1].T)
+        gg = xi_star_z - star[wi]
+        rhs = np.zeros_like(gg)
+        rhs[:, 2:] = gg[:, 1:nz - 1]
+        H = helmholtz_matrix(chw, self.pxi, tau)
+        wa = np.linalg.solve(H, rhs.T).T
+        out[:, wi] = (wa @ chw.T.T).reshape(-1)
+        out[:, xi] = (xi_star - tau * (wa @ (chw.T @ chw.Dc).T)).reshape(-1)
+        return out
