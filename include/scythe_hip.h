@@ -1,0 +1,186 @@
+/*
+ * scythe_hip.h — C ABI of libscythe_hip.so: the MI355X (gfx950) implementation of Scythe.jl's per-time-step
+ * spectral-transform hot path.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * The reference (Julia) has no FFI for this path; the seam is the pair of remote calls the master issues per step
+ * (SURVEY.md 8(b)).  Every entry point cites the reference call it replaces (paths relative to the reference tree).
+ * The Julia-side `ccall` glue a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; sx_last_error() gives the message
+ *     (the reference signals errors with Julia exceptions: src/Scythe.jl:40, src/semiimplicit.jl:745,
+ *      src/spectralGrid.jl:88-91).
+ *   - host arrays use the reference's own layouts (column-major as in Julia):
+ *        physical[point, var, deriv]   point = (ring-major, lambda, z innermost)   src/semiimplicit.jl:48, 64
+ *        spectral[index, var]          index = (z-mode, wavenumber block, radial node), node fastest
+ *     host pointers are borrowed for the duration of the call only.
+ *   - one handle per tile (= per worker process / GPU, src/semiimplicit.jl:179-184); calls on one handle are serial.
+ *   - t is the 1-based step counter of model_loop (src/semiimplicit.jl:268); it selects Euler/AB2/AB3.
+ */
+#ifndef SCYTHE_HIP_H
+#define SCYTHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SX_ABI_VERSION 1
+
+/* geometry  (GridParameters.geometry, src/spectralGrid.jl:21, 63-94) */
+enum { SX_GEOM_R = 0, SX_GEOM_RZ = 1, SX_GEOM_RL = 2, SX_GEOM_RLZ = 3 };
+
+/* radial / vertical boundary-condition codes (CubicBSpline.* / Chebyshev.* Dicts, models/ *.jl) */
+enum { SX_BC_R0 = 0, SX_BC_R1T0 = 1, SX_BC_R1T1 = 2, SX_BC_R1T2 = 3, SX_BC_R2T10 = 4, SX_BC_R2T20 = 5, SX_BC_R3 = 6,
+       SX_BC_PERIODIC = 7 };
+
+/* equation sets, selected by name in the reference (src/semiimplicit.jl:357-363) */
+enum {
+    SX_EQ_LINEAR_ADVECTION_1D = 0,   /* src/testModels.jl:1-20   */
+    SX_EQ_LINEAR_ADVECTION_RZ = 1,   /* src/testModels.jl:22-45  */
+    SX_EQ_LINEAR_ADVECTION_RL = 2,   /* src/testModels.jl:47-73  */
+    SX_EQ_LINEAR_ADVECTION_RLZ = 3,  /* src/testModels.jl:75-98  */
+    SX_EQ_ONEWAY_SW_SLAB = 4,        /* src/shallowWaterModels.jl:1-113   */
+    SX_EQ_TWOWAY_SW_SLAB = 5,        /* src/shallowWaterModels.jl:115-233 */
+    SX_EQ_ONEWAY_SW_HRBL = 6,        /* src/shallowWaterModels.jl:346-511 */
+    SX_EQ_LINEAR_ACOUSTIC_RZ = 7,    /* synthetic vehicle for semiimplicit_adjustment (src/semiimplicit.jl:521-597);
+                                        Euler_test's variable layout and implicit terms (src/testModels.jl:188-205)
+                                        with a linearised pressure-gradient force */
+    SX_EQ_NONE = 99                  /* transforms only: sx_advance copies physical[:, :, 1] into var_np1 */
+};
+
+/* physical_params, fixed positions (model.physical_params Dict, models/ *.jl) */
+enum { SX_P_G = 0, SX_P_K, SX_P_CD, SX_P_HFREE, SX_P_HB, SX_P_F, SX_P_S1, SX_P_C0, SX_P_KH, SX_P_UM, SX_P_VM,
+       SX_P_PXI_BAR, SX_NPARAMS };
+
+/* GridParameters flattened (src/spectralGrid.jl:20-45; tile construction src/semiimplicit.jl:155-169).
+ * The patch fields describe the whole domain; the tile fields select this handle's radial range. */
+typedef struct sx_grid_desc {
+    int32_t abi_version;      /* SX_ABI_VERSION */
+    int32_t geometry;         /* SX_GEOM_* */
+    double xmin, xmax;        /* patch extent */
+    int32_t num_cells;        /* patch cells; rDim = 3*num_cells, b_rDim = num_cells + 3 */
+    double l_q;               /* spline filter length (default 2.0) */
+    int32_t nvars;
+    const int32_t *bcl;       /* [nvars] patch left BC for wavenumbers k >= 1 (and for R / RZ grids) */
+    const int32_t *bcl_k0;    /* [nvars] patch left BC for wavenumber 0, or NULL = same as bcl */
+    const int32_t *bcr;       /* [nvars] patch right BC */
+    double zmin, zmax;
+    int32_t zDim, b_zDim;     /* b_zDim <= 0 selects min(zDim, floor((2 zDim - 1) / 3) + 1) */
+    const int32_t *bcb;       /* [nvars] bottom BC or NULL = R0 */
+    const int32_t *bct;       /* [nvars] top BC or NULL = R0 */
+    int32_t ring_uniform_L;   /* 0: native rings (4 + 4 ri points, kmax = ri); L > 0: every ring has L points,
+                                 kmax = min(ri, L/2 - 1), zero phase offset (SURVEY.md 8(d) "perf shape") */
+    int32_t tile_cell0;       /* first patch cell of this tile  (= spectralIndexL - 1) */
+    int32_t tile_num_cells;   /* cells in this tile */
+    int32_t tile_num;         /* informational (GridParameters.tile_num) */
+} sx_grid_desc;
+
+/* ModelParameters subset the step needs (src/Scythe.jl:8-21) */
+typedef struct sx_model_desc {
+    double ts;
+    int32_t equation_set;     /* SX_EQ_* */
+    int32_t semiimplicit;     /* options[:semiimplicit] */
+    const double *params;     /* [SX_NPARAMS] */
+    int32_t w_index, xi_index;/* 1-based variable indices of "w" and "xi" (semi-implicit only), 0 = absent */
+    int32_t col_var;          /* 1-based variable whose vertical BCs the column operators of HRBL use ("h",
+                                 src/shallowWaterModels.jl:423), 0 = variable 1 */
+} sx_model_desc;
+
+typedef struct sx_dims {
+    int64_t n_points;         /* tile gridpoints N (incl. z) */
+    int64_t n_hpoints;        /* horizontal points (N / zDim) */
+    int32_t n_vars, n_derivs, n_coord;  /* V, D, columns of getGridpoints */
+    int32_t rDim, b_rDim;     /* patch */
+    int32_t tile_rDim, tile_b_rDim;
+    int32_t zDim, b_zDim;
+    int32_t kDim, n_blocks;   /* patch kDim, 1 + 2 kDim */
+    int32_t tile_kDim, tile_n_blocks;
+    int64_t s_patch;          /* patch spectral entries per variable */
+    int64_t s_tile;           /* tile spectral entries per variable (reference tile layout) */
+    int64_t n_cols;           /* internal: V * b_zDim * n_blocks columns of the [node][col] spectral arrays */
+} sx_dims;
+
+typedef struct sx_handle sx_handle;
+
+/* --- lifetime -------------------------------------------------------------------------------------------------- */
+/* createGrid(GridParameters(...)) + createModelTile  (src/semiimplicit.jl:155-169, 44-124) */
+int sx_create(const sx_grid_desc *grid, const sx_model_desc *model, sx_handle **out);
+int sx_destroy(sx_handle *h);
+const char *sx_last_error(void);
+int sx_abi_version(void);
+/* getfield(Scythe, Symbol(equation_set)) (src/semiimplicit.jl:359-361): name -> SX_EQ_*, -1 if not in scope */
+int sx_equation_set_id(const char *name);
+int sx_get_dims(const sx_handle *h, sx_dims *out);
+/* launch on this hipStream_t (NULL = default stream) */
+int sx_set_stream(sx_handle *h, void *hip_stream);
+int sx_synchronize(sx_handle *h);
+
+/* --- geometry ---------------------------------------------------------------------------------------------------- */
+/* getGridpoints(tile) (src/semiimplicit.jl:59): out[n_points, n_coord] column-major; columns r[, lambda][, z] */
+int sx_get_gridpoints(const sx_handle *h, double *out);
+/* calcTileSizes(patch, n) (src/semiimplicit.jl:141): out[5, n] column-major rows = xmin, xmax, num_cells,
+ * spectralIndexL, gridpoint count.  Pure host helper, no handle needed. */
+int sx_calc_tile_sizes(const sx_grid_desc *patch, int32_t n_tiles, double *out);
+
+/* --- state in / out (host pointers, reference layouts) ------------------------------------------------------------- */
+/* read_physical_grid -> physical[:, v, 1]  (src/semiimplicit.jl:134): values[n_points, n_vars] */
+int sx_set_physical_values(sx_handle *h, const double *values);
+/* tile.physical (src/semiimplicit.jl:305, 290): out[n_points, n_vars, n_derivs] */
+int sx_get_physical(sx_handle *h, double *out);
+/* mtile.var_np1 (src/semiimplicit.jl:21, 731): out[n_points, n_vars] */
+int sx_get_var_np1(sx_handle *h, double *out);
+/* tile.spectral after calcTendency (src/semiimplicit.jl:323): out[s_tile, n_vars] B coefficients */
+int sx_get_tile_spectral(sx_handle *h, double *out);
+/* sharedSpectral -> device (src/semiimplicit.jl:285 input): shared[s_patch, n_vars] B coefficients */
+int sx_set_patch_spectral_b(sx_handle *h, const double *shared);
+/* mtile.patchSpectral (src/semiimplicit.jl:289): out[s_patch, n_vars] A coefficients */
+int sx_get_patch_spectral_a(sx_handle *h, double *out);
+int sx_set_patch_spectral_a(sx_handle *h, const double *a);
+
+/* --- the hot path -------------------------------------------------------------------------------------------------- */
+/* spectralTransform!(tile) on var_np1 (calcTendency, src/semiimplicit.jl:728-735) -> tile B coefficients */
+int sx_spectral_transform(sx_handle *h);
+/* splineTransform!(patchSplines, patchSpectral, gp, sharedSpectral, tile) (src/semiimplicit.jl:237, 285) */
+int sx_spline_transform(sx_handle *h);
+/* tileTransform!(patchSplines, patchSpectral, gp, tile, splineBuffer) (src/semiimplicit.jl:241, 305) */
+int sx_tile_transform(sx_handle *h);
+/* advanceTimestep up to and including calcTendency (src/semiimplicit.jl:305-317):
+ * tileTransform! -> equation set -> explicit_timestep [-> semiimplicit_adjustment] -> spectralTransform! */
+int sx_advance(sx_handle *h, int32_t t);
+/* physical_model only (src/semiimplicit.jl:357-363) on the current tile.physical */
+int sx_physics(sx_handle *h, int32_t t);
+/* checkCFL (src/semiimplicit.jl:737-751): flag = 1 if any NaN in physical[:, v, 1] */
+int sx_check_nan(sx_handle *h, int32_t *flag);
+
+/* --- tile <-> patch exchange on the device (src/semiimplicit.jl:320-329, 272-285) ---------------------------------- */
+/* The tile's B coefficients live in a [tile_b_rDim][n_cols] row-major device array (row = radial node).
+ * Rows [0, tile_num_cells) are owned (patchIndexMap), rows [tile_num_cells, +3) are the halo sent to the next
+ * tile (haloSendIndexMap); the last tile owns all its rows. */
+int sx_tile_b_device(sx_handle *h, void **dev_ptr, int64_t *n_rows, int64_t *n_cols);
+/* Make sx_spectral_transform / sx_advance write the tile's B rows at dev_ptr (e.g. inside an all-gather buffer). */
+int sx_bind_tile_b(sx_handle *h, void *dev_ptr);
+/* sharedSpectral[haloReceiveIndexMap] .+= haloReceiveBuffer (src/semiimplicit.jl:329): B rows 0..2 += recv[3][n_cols] */
+int sx_halo_add(sx_handle *h, const void *dev_recv);
+/* Source of the patch-level B for sx_spline_transform: row m of the patch is at dev_base + row_offset[m] doubles.
+ * dev_base = NULL restores the internal buffer (filled by sx_set_patch_spectral_b or, for a one-tile patch,
+ * by sx_spectral_transform). */
+int sx_bind_patch_b(sx_handle *h, const void *dev_base, const int64_t *row_offset /* [b_rDim] host */);
+/* device pointer of the patch A array [b_rDim][n_cols] */
+int sx_patch_a_device(sx_handle *h, void **dev_ptr, int64_t *n_rows, int64_t *n_cols);
+
+/* --- measurement ---------------------------------------------------------------------------------------------------- */
+/* hipEvent timers around every kernel on the handle's stream (off by default). */
+int sx_enable_timers(sx_handle *h, int32_t on);
+int sx_reset_timers(sx_handle *h);
+/* names[i] borrowed static strings; ms[i] accumulated milliseconds; calls[i] launches. Returns count via n. */
+int sx_get_timers(sx_handle *h, int32_t max, const char **names, double *ms, int64_t *calls, int32_t *n);
+/* algorithmic bytes of one launch of the named kernel (SURVEY.md 8(d) accounting), 0 if unknown */
+int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCYTHE_HIP_H */

@@ -1,0 +1,8 @@
+"""scythe.jl_amd - MI355X-native spectral-transform time stepping for Scythe.jl (hot path only).
+
+The directory name contains a dot, so import it through the `scythe_jl_amd` shim at the repo root."""
+from ._lib import load, ScytheHipError, LIB_PATH
+from .model import (CubicBSpline, Chebyshev, GridParameters, ModelParameters, Grid, createGrid, getGridpoints,
+                    calcTileSizes, num_columns, checkCFL)
+from .driver import PatchLayout, LocalExchange, DistExchange, ModelRun, integrate_model
+from .io import read_physical_grid, write_output

@@ -1,0 +1,757 @@
+// C ABI of libscythe_hip.so (declared in include/scythe_hip.h).
+#include "sx_internal.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+
+namespace sx {
+
+static thread_local std::string g_err;
+static thread_local bool g_err_set = false;
+
+void set_error(const std::string &msg) {
+    if (!g_err_set) g_err = msg;
+    g_err_set = true;
+}
+static void clear_error() { g_err_set = false; }
+static int status() { return g_err_set ? 1 : 0; }
+
+#define HIPOK(x)                                                                          \
+    do {                                                                                  \
+        hipError_t e_ = (x);                                                              \
+        if (e_ != hipSuccess) {                                                           \
+            set_error(std::string(#x) + ": " + hipGetErrorString(e_));                    \
+            return 1;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+template <class T>
+static bool dalloc(sx_handle *h, T **p, size_t count, bool zero = true) {
+    void *d = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) {
+        set_error(std::string("hipMalloc failed: ") + hipGetErrorString(e));
+        return false;
+    }
+    if (zero && hipMemset(d, 0, bytes) != hipSuccess) {
+        set_error("hipMemset failed");
+        return false;
+    }
+    h->allocs.push_back(d);
+    h->dev_bytes += bytes;
+    *p = (T *)d;
+    return true;
+}
+
+template <class T>
+static bool upload(sx_handle *h, T **p, const std::vector<T> &v) {
+    if (!dalloc(h, p, v.size(), false)) return false;
+    if (!v.empty() && hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("hipMemcpy H2D failed");
+        return false;
+    }
+    return true;
+}
+
+static std::vector<double> transpose(const std::vector<double> &m, int n) {
+    std::vector<double> t((size_t)n * n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) t[(size_t)j * n + i] = m[(size_t)i * n + j];
+    return t;
+}
+
+// ---- timers
+int timer_id(sx_handle *h, const char *name) {
+    for (size_t i = 0; i < h->timers.size(); i++)
+        if (h->timers[i].name == name || !std::strcmp(h->timers[i].name, name)) return (int)i;
+    Timer t;
+    t.name = name;
+    h->timers.push_back(t);
+    return (int)h->timers.size() - 1;
+}
+
+static hipEvent_t get_event(sx_handle *h) {
+    if (!h->event_pool.empty()) {
+        hipEvent_t e = h->event_pool.back();
+        h->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) set_error("hipEventCreate failed");
+    return e;
+}
+
+void timer_begin(sx_handle *h, int id) {
+    if (!h->timers_on) return;
+    if (h->pending.size() >= 8192) timers_flush(h);
+    PendingEvent p;
+    p.timer = id;
+    p.a = get_event(h);
+    p.b = get_event(h);
+    hipEventRecord(p.a, h->stream);
+    h->pending.push_back(p);
+}
+
+void timer_end(sx_handle *h) {
+    if (!h->timers_on || h->pending.empty()) return;
+    hipEventRecord(h->pending.back().b, h->stream);
+}
+
+void timers_flush(sx_handle *h) {
+    for (auto &p : h->pending) {
+        float ms = 0.f;
+        hipEventSynchronize(p.b);
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            h->timers[p.timer].ms += ms;
+            h->timers[p.timer].calls += 1;
+        }
+        h->event_pool.push_back(p.a);
+        h->event_pool.push_back(p.b);
+    }
+    h->pending.clear();
+}
+
+static const int DERIV_SLOTS[4][7] = {
+    /* u r rr l ll z zz */
+    {0, 1, 2, -1, -1, -1, -1},   // R
+    {0, 1, 2, -1, -1, 3, 4},     // RZ
+    {0, 1, 2, 3, 4, -1, -1},     // RL
+    {0, 1, 2, 3, 4, 5, 6},       // RLZ
+};
+
+static int default_bzdim(int zDim) {
+    int b = (int)std::floor((2.0 * zDim - 1.0) / 3.0) + 1;
+    return std::min(zDim, b);
+}
+
+// reference layout index of (zm, blk, node) inside one variable's spectral column
+static inline int64_t ref_index(int zm, int blk, int node, int K2, int nb) { return ((int64_t)zm * K2 + blk) * nb + node; }
+
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" {
+
+const char *sx_last_error(void) { return g_err.c_str(); }
+int sx_abi_version(void) { return SX_ABI_VERSION; }
+
+int sx_equation_set_id(const char *name) {
+    static const std::map<std::string, int> ids = {
+        {"LinearAdvection1D", SX_EQ_LINEAR_ADVECTION_1D},
+        {"LinearAdvectionRZ", SX_EQ_LINEAR_ADVECTION_RZ},
+        {"LinearAdvectionRL", SX_EQ_LINEAR_ADVECTION_RL},
+        {"LinearAdvectionRLZ", SX_EQ_LINEAR_ADVECTION_RLZ},
+        {"Oneway_ShallowWater_Slab", SX_EQ_ONEWAY_SW_SLAB},
+        {"Twoway_ShallowWater_Slab", SX_EQ_TWOWAY_SW_SLAB},
+        {"Oneway_ShallowWater_HeightResolvedBL", SX_EQ_ONEWAY_SW_HRBL},
+        {"LinearAcousticRZ", SX_EQ_LINEAR_ACOUSTIC_RZ},
+        {"None", SX_EQ_NONE},
+    };
+    if (!name) return -1;
+    auto it = ids.find(name);
+    return it == ids.end() ? -1 : it->second;
+}
+
+static int tile_sizes(const sx_grid_desc *g, int n, std::vector<int> &cells) {
+    // calcTileSizes: R / RZ split the cells evenly, RL / RLZ balance gridpoints (SURVEY.md 8(c) "Layouts").
+    const int nc = g->num_cells;
+    if (n < 1 || nc < 3 * n) {
+        set_error("calcTileSizes: need at least 3 cells per tile");
+        return 1;
+    }
+    const bool has_l = (g->geometry == SX_GEOM_RL || g->geometry == SX_GEOM_RLZ);
+    cells.assign(n, 0);
+    if (!has_l || g->ring_uniform_L > 0) {
+        for (int t = 0; t < n; t++) cells[t] = nc / n + (t < nc % n ? 1 : 0);
+        return 0;
+    }
+    std::vector<double> cum(nc + 1, 0.0);
+    for (int c = 0; c < nc; c++) {
+        double pts = 0;
+        for (int mu = 0; mu < MUBAR; mu++) pts += 4.0 + 4.0 * (c * MUBAR + mu + 1);
+        cum[c + 1] = cum[c] + pts;
+    }
+    int c0 = 0;
+    for (int t = 0; t < n; t++) {
+        int c1;
+        if (t == n - 1) {
+            c1 = nc;
+        } else {
+            const double target = cum[nc] * (t + 1) / n;
+            c1 = c0 + 3;
+            while (c1 < nc - 3 * (n - 1 - t) && cum[c1] < target) c1++;
+            if (c1 > c0 + 3 && (cum[c1] - target) > (target - cum[c1 - 1])) c1--;
+        }
+        cells[t] = c1 - c0;
+        c0 = c1;
+    }
+    return 0;
+}
+
+int sx_calc_tile_sizes(const sx_grid_desc *g, int32_t n, double *out) {
+    clear_error();
+    if (!g || !out) { set_error("null argument"); return 1; }
+    std::vector<int> cells;
+    if (tile_sizes(g, n, cells)) return 1;
+    const double DX = (g->xmax - g->xmin) / g->num_cells;
+    const bool has_l = (g->geometry == SX_GEOM_RL || g->geometry == SX_GEOM_RLZ);
+    const bool has_z = (g->geometry == SX_GEOM_RZ || g->geometry == SX_GEOM_RLZ);
+    int c0 = 0;
+    for (int t = 0; t < n; t++) {
+        double pts = 0;
+        for (int r = c0 * MUBAR; r < (c0 + cells[t]) * MUBAR; r++) {
+            int L, km;
+            double off;
+            ring_table(has_l, g->ring_uniform_L, r + 1, L, km, off);
+            pts += L;
+        }
+        if (has_z) pts *= g->zDim;
+        out[t * 5 + 0] = g->xmin + c0 * DX;
+        out[t * 5 + 1] = g->xmin + (c0 + cells[t]) * DX;
+        out[t * 5 + 2] = cells[t];
+        out[t * 5 + 3] = c0 + 1;
+        out[t * 5 + 4] = pts;
+        c0 += cells[t];
+    }
+    return 0;
+}
+
+int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
+    clear_error();
+    if (!g || !m || !out) { set_error("null argument"); return 1; }
+    if (g->abi_version != SX_ABI_VERSION) { set_error("sx_grid_desc.abi_version mismatch"); return 1; }
+    if (g->geometry < SX_GEOM_R || g->geometry > SX_GEOM_RLZ) { set_error("Unknown geometry"); return 1; }
+    if (g->num_cells < 3 || g->nvars < 1 || !(g->xmax > g->xmin)) { set_error("invalid grid parameters"); return 1; }
+    if (g->tile_cell0 < 0 || g->tile_num_cells < 1 || g->tile_cell0 + g->tile_num_cells > g->num_cells) {
+        set_error("tile range outside the patch");
+        return 1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        set_error("no HIP device available: libscythe_hip has no CPU fallback");
+        return 1;
+    }
+    sx_handle *h = new sx_handle();
+    std::string err;
+    h->geom = g->geometry;
+    h->has_l = (g->geometry == SX_GEOM_RL || g->geometry == SX_GEOM_RLZ);
+    h->has_z = (g->geometry == SX_GEOM_RZ || g->geometry == SX_GEOM_RLZ);
+    h->xmin = g->xmin; h->xmax = g->xmax; h->nc = g->num_cells;
+    h->DX = (g->xmax - g->xmin) / g->num_cells;
+    h->l_q = g->l_q > 0 ? g->l_q : 2.0;
+    h->V = g->nvars;
+    h->rDim = MUBAR * h->nc; h->b_rDim = h->nc + 3;
+    h->uniform_L = h->has_l ? g->ring_uniform_L : 0;
+    h->cell0 = g->tile_cell0; h->ncells = g->tile_num_cells; h->tile_num = g->tile_num;
+    h->nrings = MUBAR * h->ncells; h->nbt = h->ncells + 3;
+    for (int i = 0; i < 7; i++) h->slot[i] = DERIV_SLOTS[h->geom][i];
+    h->D = h->geom == SX_GEOM_R ? 3 : h->geom == SX_GEOM_RLZ ? 7 : 5;
+    h->ncoord = 1 + h->has_l + h->has_z;
+    if (h->has_z) {
+        h->nz = g->zDim;
+        h->Zb = g->b_zDim > 0 ? g->b_zDim : default_bzdim(g->zDim);
+        h->zmin = g->zmin; h->zmax = g->zmax;
+        h->nsz = 3;
+        if (h->nz < 4 || h->nz > 256 || h->Zb > h->nz || !(g->zmax > g->zmin)) {
+            set_error("invalid vertical grid (need 4 <= zDim <= 256, b_zDim <= zDim, zmax > zmin)");
+            delete h;
+            return 1;
+        }
+    }
+    if (h->uniform_L && (h->uniform_L < 4 || (h->uniform_L & 1))) { set_error("ring_uniform_L must be even and >= 4"); delete h; return 1; }
+    auto bcv = [&](const int32_t *p, std::vector<int> &dst) {
+        dst.assign(h->V, SX_BC_R0);
+        if (p) for (int v = 0; v < h->V; v++) dst[v] = p[v];
+    };
+    bcv(g->bcl, h->bcl); bcv(g->bcl_k0 ? g->bcl_k0 : g->bcl, h->bcl0); bcv(g->bcr, h->bcr); bcv(g->bcb, h->bcb); bcv(g->bct, h->bct);
+    // model
+    h->ts = m->ts; h->eq = m->equation_set; h->semi = m->semiimplicit;
+    h->w_index = m->w_index; h->xi_index = m->xi_index; h->col_var = m->col_var > 0 ? m->col_var : 1;
+    if (m->params) std::memcpy(h->par, m->params, sizeof(double) * SX_NPARAMS);
+    {
+        const int eq = h->eq;
+        const int need_geom = (eq == SX_EQ_LINEAR_ADVECTION_1D) ? SX_GEOM_R
+                            : (eq == SX_EQ_LINEAR_ADVECTION_RZ || eq == SX_EQ_LINEAR_ACOUSTIC_RZ) ? SX_GEOM_RZ
+                            : (eq == SX_EQ_LINEAR_ADVECTION_RL || eq == SX_EQ_ONEWAY_SW_SLAB || eq == SX_EQ_TWOWAY_SW_SLAB) ? SX_GEOM_RL
+                            : (eq == SX_EQ_LINEAR_ADVECTION_RLZ || eq == SX_EQ_ONEWAY_SW_HRBL) ? SX_GEOM_RLZ : -1;
+        const int need_vars = (eq == SX_EQ_LINEAR_ADVECTION_RZ) ? 4 : (eq == SX_EQ_LINEAR_ADVECTION_RL || eq == SX_EQ_LINEAR_ADVECTION_RLZ) ? 3
+                            : (eq == SX_EQ_ONEWAY_SW_SLAB || eq == SX_EQ_TWOWAY_SW_SLAB || eq == SX_EQ_ONEWAY_SW_HRBL) ? 6
+                            : (eq == SX_EQ_LINEAR_ACOUSTIC_RZ) ? 5 : 1;
+        if (eq != SX_EQ_NONE && need_geom < 0) { set_error("equation set not in scope"); delete h; return 1; }
+        if (eq != SX_EQ_NONE && (need_geom != h->geom || h->V < need_vars)) {
+            set_error("equation set does not match the grid geometry / variable count");
+            delete h;
+            return 1;
+        }
+        if (h->semi && (!h->has_z || h->w_index < 1 || h->xi_index < 1 || h->w_index > h->V || h->xi_index > h->V || h->Zb != h->nz)) {
+            set_error("semi-implicit adjustment needs an RZ/RLZ grid, w and xi variables and b_zDim == zDim");
+            delete h;
+            return 1;
+        }
+    }
+#define FAIL()            \
+    do {                  \
+        sx_destroy(h);    \
+        return 1;         \
+    } while (0)
+
+    // ---- ring tables (tile rings; kDim / K2 are patch-level)
+    h->kDim = 0;
+    for (int r = 0; r < h->rDim; r++) {
+        int L, km;
+        double off;
+        ring_table(h->has_l, h->uniform_L, r + 1, L, km, off);
+        h->kDim = std::max(h->kDim, km);
+    }
+    h->K2 = 1 + 2 * h->kDim;
+    h->hL.resize(h->nrings); h->hkmax.resize(h->nrings); h->hoff.resize(h->nrings); h->hpstart.resize(h->nrings);
+    std::vector<int64_t> twoff(h->nrings), phoff(h->nrings);
+    std::vector<double2> tw, ph;
+    int64_t pcount = 0;
+    h->kDim_t = 0;
+    std::map<int, int64_t> tw_of_L;
+    for (int i = 0; i < h->nrings; i++) {
+        int L, km;
+        double off;
+        ring_table(h->has_l, h->uniform_L, h->cell0 * MUBAR + i + 1, L, km, off);
+        h->hL[i] = L; h->hkmax[i] = km; h->hoff[i] = off; h->hpstart[i] = pcount;
+        pcount += L;
+        h->kDim_t = std::max(h->kDim_t, km);
+        h->L_max = std::max(h->L_max, L);
+        auto it = tw_of_L.find(L);
+        if (it == tw_of_L.end()) {
+            tw_of_L[L] = (int64_t)tw.size();
+            twoff[i] = (int64_t)tw.size();
+            for (int j = 0; j < L; j++) tw.push_back(make_double2(std::cos(2.0 * M_PI * j / L), std::sin(2.0 * M_PI * j / L)));
+        } else {
+            twoff[i] = it->second;
+        }
+        phoff[i] = (int64_t)ph.size();
+        for (int k = 0; k <= km; k++) ph.push_back(make_double2(std::cos(k * off), std::sin(k * off)));
+    }
+    h->kmax_max = h->kDim_t;
+    h->K2t = 1 + 2 * h->kDim_t;
+    h->Nh = pcount;
+    h->N = pcount * h->nz;
+    h->C = (int64_t)h->V * h->Zb * h->K2;
+    h->S_patch = (int64_t)h->Zb * h->K2 * h->b_rDim;
+    h->S_tile = (int64_t)h->Zb * h->K2t * h->nbt;
+
+    // ---- radial tables
+    double phi[4][MUBAR][4], wq[MUBAR];
+    basis_tables(h->DX, phi);
+    quad_weights(h->DX, wq);
+    std::vector<double> hphi((size_t)3 * h->nrings * 4), hwq(h->nrings), hr(h->Nh), hcos(h->Nh), hsin(h->Nh);
+    const double off3[MUBAR] = {-std::sqrt(3.0 / 5.0) / 2.0, 0.0, std::sqrt(3.0 / 5.0) / 2.0};
+    for (int i = 0; i < h->nrings; i++) {
+        const int mu = i % MUBAR, c = h->cell0 + i / MUBAR;
+        for (int d = 0; d < 3; d++)
+            for (int j = 0; j < 4; j++) hphi[((size_t)d * h->nrings + i) * 4 + j] = phi[d][mu][j];
+        hwq[i] = wq[mu];
+        const double r = h->xmin + h->DX * (c + 0.5 + off3[mu]);
+        for (int l = 0; l < h->hL[i]; l++) {
+            const double lam = h->hoff[i] + 2.0 * M_PI * l / h->hL[i];
+            hr[h->hpstart[i] + l] = r;
+            hcos[h->hpstart[i] + l] = std::cos(lam);
+            hsin[h->hpstart[i] + l] = std::sin(lam);
+        }
+    }
+    if (!upload(h, &h->d_phi, hphi) || !upload(h, &h->d_wq, hwq) || !upload(h, &h->d_r, hr) || !upload(h, &h->d_cosl, hcos) ||
+        !upload(h, &h->d_sinl, hsin) || !upload(h, &h->d_L, h->hL) || !upload(h, &h->d_kmax, h->hkmax) ||
+        !upload(h, &h->d_pstart, h->hpstart) || !upload(h, &h->d_twoff, twoff) || !upload(h, &h->d_phoff, phoff) ||
+        !upload(h, &h->d_tw, tw) || !upload(h, &h->d_ph, ph))
+        FAIL();
+
+    // ---- spline classes
+    std::vector<SplineClass> classes;
+    std::vector<int> cls((size_t)h->V * 2);
+    for (int v = 0; v < h->V; v++)
+        for (int q = 0; q < 2; q++) {
+            const int bl = q == 0 ? h->bcl0[v] : h->bcl[v], br = h->bcr[v];
+            int found = -1;
+            for (size_t c = 0; c < classes.size(); c++)
+                if (classes[c].bcl == bl && classes[c].bcr == br) found = (int)c;
+            if (found < 0) {
+                SplineClass sc;
+                if (!build_spline_class(h->nc, h->DX, h->l_q, bl, br, sc, err)) { set_error(err); FAIL(); }
+                classes.push_back(sc);
+                found = (int)classes.size() - 1;
+            }
+            cls[(size_t)v * 2 + q] = found;
+        }
+    h->ncls = (int)classes.size();
+    {
+        const int nb = h->b_rDim;
+        std::vector<int> cmeta((size_t)h->ncls * 4);
+        std::vector<double> gl((size_t)h->ncls * 6), gr((size_t)h->ncls * 6), Lb((size_t)h->ncls * nb * 4), La((size_t)h->ncls * 3 * nb);
+        for (int c = 0; c < h->ncls; c++) {
+            const SplineClass &s = classes[c];
+            cmeta[c * 4 + 0] = s.nfree; cmeta[c * 4 + 1] = s.periodic; cmeta[c * 4 + 2] = s.rl; cmeta[c * 4 + 3] = s.rr;
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 2; j++) { gl[c * 6 + i * 2 + j] = s.gl[i][j]; gr[c * 6 + i * 2 + j] = s.gr[i][j]; }
+            std::copy(s.Lband.begin(), s.Lband.end(), Lb.begin() + (size_t)c * nb * 4);
+            std::copy(s.Larrow.begin(), s.Larrow.end(), La.begin() + (size_t)c * 3 * nb);
+        }
+        if (!upload(h, &h->d_cls, cls) || !upload(h, &h->d_cmeta, cmeta) || !upload(h, &h->d_gl, gl) || !upload(h, &h->d_gr, gr) ||
+            !upload(h, &h->d_Lband, Lb) || !upload(h, &h->d_Larrow, La))
+            FAIL();
+    }
+
+    // ---- Chebyshev operators
+    if (h->has_z) {
+        const int nz = h->nz, Zb = h->Zb;
+        std::vector<double> Mz((size_t)h->V * 3 * nz * Zb);
+        std::vector<ChebOps> ops(h->V);
+        for (int v = 0; v < h->V; v++) {
+            if (!build_cheb_ops(h->zmin, h->zmax, nz, Zb, h->bcb[v], h->bct[v], ops[v], err)) { set_error(err); FAIL(); }
+            for (int d = 0; d < 3; d++)
+                std::copy(ops[v].M[d].begin(), ops[v].M[d].end(), Mz.begin() + ((size_t)v * 3 + d) * nz * Zb);
+        }
+        const ChebOps &cop = ops[h->col_var - 1 < h->V ? h->col_var - 1 : 0];
+        std::vector<double> zv = cop.z;
+        if (!upload(h, &h->d_Mz, Mz) || !upload(h, &h->d_CB, ops[0].CB) || !upload(h, &h->d_z, zv)) FAIL();
+        if (h->semi) {
+            const ChebOps &ox = ops[h->xi_index - 1], &ow = ops[h->w_index - 1];
+            if (!upload(h, &h->d_MrecT, transpose(ox.Mrec, nz)) || !upload(h, &h->d_MdzT, transpose(ox.Mdz, nz))) FAIL();
+            h->tau[0] = 0.5 * h->ts;     // first step: trapezoidal (src/semiimplicit.jl:544-548)
+            h->tau[1] = 1.25 * h->ts;    // AI2*        (src/semiimplicit.jl:549-558, 96)
+            for (int q = 0; q < 2; q++) {
+                std::vector<double> W, X;
+                if (!build_helmholtz(ow, h->par[SX_P_PXI_BAR], h->tau[q], W, X, err)) { set_error(err); FAIL(); }
+                if (!upload(h, &h->d_WT[q], transpose(W, nz)) || !upload(h, &h->d_XT[q], transpose(X, nz))) FAIL();
+            }
+        } else {
+            if (!upload(h, &h->d_MintT, transpose(cop.Mint, nz)) || !upload(h, &h->d_MdzT, transpose(cop.Mdz, nz))) FAIL();
+        }
+    } else {
+        std::vector<double> one(1, 0.0);
+        if (!upload(h, &h->d_z, one)) FAIL();
+    }
+
+    // ---- state
+    const int64_t C = h->C, N = h->N;
+    if (!dalloc(h, &h->d_A, (size_t)h->b_rDim * C) || !dalloc(h, &h->d_Bfull, (size_t)h->b_rDim * C) ||
+        !dalloc(h, &h->d_rowoff, (size_t)h->b_rDim) || !dalloc(h, &h->d_phys, (size_t)h->D * h->V * N) ||
+        !dalloc(h, &h->d_np1, (size_t)h->V * N) || !dalloc(h, &h->d_flag, 1))
+        FAIL();
+    for (int i = 0; i < 3; i++) {
+        if (!dalloc(h, &h->d_E[i], (size_t)h->V * N)) FAIL();
+        if (h->semi && !dalloc(h, &h->d_I[i], (size_t)h->V * N)) FAIL();
+    }
+    if (!dalloc(h, &h->d_Fl, (size_t)h->nrings * h->V * h->nz * h->K2)) FAIL();
+    if (h->has_z) {
+        if (!dalloc(h, &h->d_Az, (size_t)h->nbt * h->V * 3 * h->nz * h->K2) || !dalloc(h, &h->d_Bz, (size_t)h->nbt * h->V * h->nz * h->K2))
+            FAIL();
+    }
+    if (h->ncells == h->nc) {
+        h->d_Btile = h->d_Bfull;                      // one-tile patch: the tile's B rows are the patch's B rows
+    } else {
+        if (!dalloc(h, &h->d_Btile_own, (size_t)h->nbt * C)) FAIL();
+        h->d_Btile = h->d_Btile_own;
+    }
+    if (sx_bind_patch_b(h, nullptr, nullptr)) FAIL();
+    *out = h;
+    return status();
+#undef FAIL
+}
+
+int sx_destroy(sx_handle *h) {
+    if (!h) return 0;
+    hipDeviceSynchronize();
+    for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : h->event_pool) hipEventDestroy(e);
+    for (void *p : h->allocs) hipFree(p);
+    delete h;
+    return 0;
+}
+
+int sx_get_dims(const sx_handle *h, sx_dims *o) {
+    clear_error();
+    if (!h || !o) { set_error("null argument"); return 1; }
+    o->n_points = h->N; o->n_hpoints = h->Nh; o->n_vars = h->V; o->n_derivs = h->D; o->n_coord = h->ncoord;
+    o->rDim = h->rDim; o->b_rDim = h->b_rDim; o->tile_rDim = h->nrings; o->tile_b_rDim = h->nbt;
+    o->zDim = h->has_z ? h->nz : 0; o->b_zDim = h->has_z ? h->Zb : 0;
+    o->kDim = h->kDim; o->n_blocks = h->K2; o->tile_kDim = h->kDim_t; o->tile_n_blocks = h->K2t;
+    o->s_patch = h->S_patch; o->s_tile = h->S_tile; o->n_cols = h->C;
+    return 0;
+}
+
+int sx_set_stream(sx_handle *h, void *s) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    h->stream = (hipStream_t)s;
+    return 0;
+}
+
+int sx_synchronize(sx_handle *h) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    HIPOK(hipStreamSynchronize(h->stream));
+    return status();
+}
+
+int sx_get_gridpoints(const sx_handle *h, double *out) {
+    clear_error();
+    if (!h || !out) { set_error("null argument"); return 1; }
+    const double off3[MUBAR] = {-std::sqrt(3.0 / 5.0) / 2.0, 0.0, std::sqrt(3.0 / 5.0) / 2.0};
+    std::vector<double> z(h->nz, 0.0);
+    if (h->has_z)
+        for (int n = 0; n < h->nz; n++)
+            z[n] = std::cos(n * M_PI / (h->nz - 1)) * (-0.5 * (h->zmax - h->zmin)) + 0.5 * (h->zmin + h->zmax);
+    int64_t p = 0;
+    for (int i = 0; i < h->nrings; i++) {
+        const int mu = i % MUBAR, c = h->cell0 + i / MUBAR;
+        const double r = h->xmin + h->DX * (c + 0.5 + off3[mu]);
+        for (int l = 0; l < h->hL[i]; l++) {
+            const double lam = h->hoff[i] + 2.0 * M_PI * l / h->hL[i];
+            for (int k = 0; k < h->nz; k++, p++) {
+                int col = 0;
+                out[p] = r;
+                if (h->has_l) out[(int64_t)(++col) * h->N + p] = lam;
+                if (h->has_z) out[(int64_t)(++col) * h->N + p] = z[k];
+            }
+        }
+    }
+    return 0;
+}
+
+int sx_set_physical_values(sx_handle *h, const double *values) {
+    clear_error();
+    if (!h || !values) { set_error("null argument"); return 1; }
+    HIPOK(hipMemcpyAsync(h->d_np1, values, sizeof(double) * h->V * h->N, hipMemcpyHostToDevice, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    return status();
+}
+
+int sx_get_physical(sx_handle *h, double *out) {
+    clear_error();
+    if (!h || !out) { set_error("null argument"); return 1; }
+    HIPOK(hipMemcpyAsync(out, h->d_phys, sizeof(double) * h->D * h->V * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    return status();
+}
+
+int sx_get_var_np1(sx_handle *h, double *out) {
+    clear_error();
+    if (!h || !out) { set_error("null argument"); return 1; }
+    HIPOK(hipMemcpyAsync(out, h->d_np1, sizeof(double) * h->V * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    return status();
+}
+
+int sx_get_tile_spectral(sx_handle *h, double *out) {
+    clear_error();
+    if (!h || !out) { set_error("null argument"); return 1; }
+    std::vector<double> tmp((size_t)h->nbt * h->C);
+    HIPOK(hipMemcpyAsync(tmp.data(), h->d_Btile, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    for (int v = 0; v < h->V; v++)
+        for (int zm = 0; zm < h->Zb; zm++)
+            for (int blk = 0; blk < h->K2t; blk++)
+                for (int j = 0; j < h->nbt; j++)
+                    out[(int64_t)v * h->S_tile + ref_index(zm, blk, j, h->K2t, h->nbt)] =
+                        tmp[(size_t)j * h->C + ((size_t)v * h->Zb + zm) * h->K2 + blk];
+    return status();
+}
+
+static int patch_to_device(sx_handle *h, const double *src, double *dst) {
+    std::vector<double> tmp((size_t)h->b_rDim * h->C);
+    for (int v = 0; v < h->V; v++)
+        for (int zm = 0; zm < h->Zb; zm++)
+            for (int blk = 0; blk < h->K2; blk++)
+                for (int m = 0; m < h->b_rDim; m++)
+                    tmp[(size_t)m * h->C + ((size_t)v * h->Zb + zm) * h->K2 + blk] =
+                        src[(int64_t)v * h->S_patch + ref_index(zm, blk, m, h->K2, h->b_rDim)];
+    HIPOK(hipMemcpyAsync(dst, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    return status();
+}
+
+int sx_set_patch_spectral_b(sx_handle *h, const double *shared) {
+    clear_error();
+    if (!h || !shared) { set_error("null argument"); return 1; }
+    return patch_to_device(h, shared, h->d_Bfull);
+}
+
+int sx_set_patch_spectral_a(sx_handle *h, const double *a) {
+    clear_error();
+    if (!h || !a) { set_error("null argument"); return 1; }
+    return patch_to_device(h, a, h->d_A);
+}
+
+int sx_get_patch_spectral_a(sx_handle *h, double *out) {
+    clear_error();
+    if (!h || !out) { set_error("null argument"); return 1; }
+    std::vector<double> tmp((size_t)h->b_rDim * h->C);
+    HIPOK(hipMemcpyAsync(tmp.data(), h->d_A, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    for (int v = 0; v < h->V; v++)
+        for (int zm = 0; zm < h->Zb; zm++)
+            for (int blk = 0; blk < h->K2; blk++)
+                for (int m = 0; m < h->b_rDim; m++)
+                    out[(int64_t)v * h->S_patch + ref_index(zm, blk, m, h->K2, h->b_rDim)] =
+                        tmp[(size_t)m * h->C + ((size_t)v * h->Zb + zm) * h->K2 + blk];
+    return status();
+}
+
+int sx_spectral_transform(sx_handle *h) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    launch_fl_forward(h);
+    launch_sb(h);
+    launch_zf(h);
+    return status();
+}
+
+int sx_spline_transform(sx_handle *h) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    launch_solve(h);
+    return status();
+}
+
+int sx_tile_transform(sx_handle *h) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    launch_zinv(h);
+    launch_rl_inverse(h);
+    return status();
+}
+
+int sx_physics(sx_handle *h, int32_t t) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    if (t < 1) { set_error("t is 1-based"); return 1; }
+    launch_physics(h, t);
+    return status();
+}
+
+int sx_advance(sx_handle *h, int32_t t) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    if (t < 1) { set_error("t is 1-based"); return 1; }
+    launch_zinv(h);
+    launch_rl_inverse(h);
+    launch_physics(h, t);
+    launch_fl_forward(h);
+    launch_sb(h);
+    launch_zf(h);
+    return status();
+}
+
+int sx_check_nan(sx_handle *h, int32_t *flag) {
+    clear_error();
+    if (!h || !flag) { set_error("null argument"); return 1; }
+    launch_nan_check(h);
+    int f = 0;
+    HIPOK(hipMemcpyAsync(&f, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    *flag = f;
+    return status();
+}
+
+int sx_tile_b_device(sx_handle *h, void **p, int64_t *rows, int64_t *cols) {
+    clear_error();
+    if (!h || !p) { set_error("null argument"); return 1; }
+    *p = h->d_Btile;
+    if (rows) *rows = h->nbt;
+    if (cols) *cols = h->C;
+    return 0;
+}
+
+int sx_bind_tile_b(sx_handle *h, void *p) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    h->d_Btile = p ? (double *)p : (h->d_Btile_own ? h->d_Btile_own : h->d_Bfull);
+    return 0;
+}
+
+int sx_halo_add(sx_handle *h, const void *recv) {
+    clear_error();
+    if (!h || !recv) { set_error("null argument"); return 1; }
+    launch_halo_add(h, (const double *)recv);
+    return status();
+}
+
+int sx_bind_patch_b(sx_handle *h, const void *base, const int64_t *rowoff) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    std::vector<int64_t> ro(h->b_rDim);
+    if (base && rowoff) {
+        for (int m = 0; m < h->b_rDim; m++) ro[m] = rowoff[m];
+        h->d_Bsrc = (const double *)base;
+    } else {
+        for (int m = 0; m < h->b_rDim; m++) ro[m] = (int64_t)m * h->C;
+        h->d_Bsrc = h->d_Bfull;
+    }
+    HIPOK(hipMemcpy(h->d_rowoff, ro.data(), sizeof(int64_t) * ro.size(), hipMemcpyHostToDevice));
+    return status();
+}
+
+int sx_patch_a_device(sx_handle *h, void **p, int64_t *rows, int64_t *cols) {
+    clear_error();
+    if (!h || !p) { set_error("null argument"); return 1; }
+    *p = h->d_A;
+    if (rows) *rows = h->b_rDim;
+    if (cols) *cols = h->C;
+    return 0;
+}
+
+int sx_enable_timers(sx_handle *h, int32_t on) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    if (!on) timers_flush(h);
+    h->timers_on = on;
+    return 0;
+}
+
+int sx_reset_timers(sx_handle *h) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    timers_flush(h);
+    for (auto &t : h->timers) { t.ms = 0; t.calls = 0; }
+    return 0;
+}
+
+int sx_get_timers(sx_handle *h, int32_t max, const char **names, double *ms, int64_t *calls, int32_t *n) {
+    clear_error();
+    if (!h || !n) { set_error("null argument"); return 1; }
+    timers_flush(h);
+    int cnt = 0;
+    for (auto &t : h->timers) {
+        if (cnt >= max) break;
+        if (names) names[cnt] = t.name;
+        if (ms) ms[cnt] = t.ms;
+        if (calls) calls[cnt] = t.calls;
+        cnt++;
+    }
+    *n = cnt;
+    return 0;
+}
+
+int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
+    clear_error();
+    if (!h || !name || !bytes) { set_error("null argument"); return 1; }
+    // Algorithmic bytes per launch (fp64), counting each array once (DESIGN.md "Kernels and rooflines").
+    const double w = 8.0, N = (double)h->N, V = h->V, D = h->D;
+    const double S_tile = (double)h->nbt * h->C, S_patch = (double)h->b_rDim * h->C;
+    const double az = h->has_z ? (double)h->nbt * h->V * 3 * h->nz * h->K2 : S_tile;
+    const double fl = (double)h->nrings * h->V * h->nz * h->K2, bz = (double)h->nbt * h->V * h->nz * h->K2;
+    std::string k(name);
+    double b = 0;
+    if (k == "k_rl_inverse") b = w * (N * V * D + az);              // write physical, read the z-inverted coefficients
+    else if (k == "k_zinv") b = w * (S_tile + az);
+    else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") b = w * N * V * (D + 4.0);  // read physical, E_nm1, E_nm2; write E_n, var_np1
+    else if (k == "k_fl_forward") b = w * (N * V + fl);
+    else if (k == "k_sb") b = w * (fl + bz);
+    else if (k == "k_zf") b = w * (bz + S_tile);
+    else if (k == "k_solve") b = w * 4.0 * S_patch;                 // read B, write y, read y, write A
+    else if (k == "k_semiimplicit") b = w * N * 2.0 * 5.0;
+    *bytes = b;
+    return 0;
+}
+
+}  // extern "C"

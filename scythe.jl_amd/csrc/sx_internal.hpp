@@ -1,0 +1,123 @@
+// Internal declarations of libscythe_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "scythe_hip.h"
+
+namespace sx {
+
+constexpr int MUBAR = 3;   // CubicBSpline.mubar: mish points per cell (src/spectralGrid.jl:24)
+
+// ---- host-side operator construction (sx_setup.cpp) ---------------------------------------------------------------
+struct SplineClass {
+    int bcl = 0, bcr = 0;
+    int nfree = 0, periodic = 0, rl = 0, rr = 0;
+    double gl[3][2] = {}, gr[3][2] = {};   // dependent boundary coefficients in terms of the first/last two free ones
+    std::vector<double> Lband;             // [b_rDim][4]  L[i][i-3..i]
+    std::vector<double> Larrow;            // [3][b_rDim]  last three rows of L (periodic only)
+};
+
+struct ChebOps {
+    int bcb = 0, bct = 0;
+    std::vector<double> z;       // [nz] gridpoints, index 0 = bottom
+    std::vector<double> T;       // [nz][nz]  coefficients -> values              (Chebyshev.dct_matrix)
+    std::vector<double> Dc;      // [nz][nz]  coefficient-space d/dz
+    std::vector<double> CB;      // [Zb][nz]  values -> truncated b
+    std::vector<double> CA;      // [nz][Zb]  b -> a (padding + BC projection)
+    std::vector<double> M[3];    // [nz][Zb]  b -> value, d/dz, d2/dz2
+    std::vector<double> Mint;    // [nz][nz]  values -> (CB, CA, CIInt) integral from the bottom
+    std::vector<double> Mdz;     // [nz][nz]  values -> (CB, CA, CIx) truncated derivative
+    std::vector<double> Mrec;    // [nz][nz]  values -> (CB, CA, CI) truncated reconstruction
+};
+
+void basis_tables(double DX, double phi[4][MUBAR][4]);
+void quad_weights(double DX, double w[MUBAR]);
+int bc_rank(int bc);
+bool build_spline_class(int nc, double DX, double l_q, int bcl, int bcr, SplineClass &out, std::string &err);
+bool build_cheb_ops(double zmin, double zmax, int nz, int Zb, int bcb, int bct, ChebOps &out, std::string &err);
+// Helmholtz operator of calc_Helmholtz_semiimplicit_matrix (src/semiimplicit.jl:768-781) folded with the
+// collocation matrices:  Wmat = T H^-1,  Xmat = T Dc H^-1   (both [nz][nz], acting on the shifted right-hand side)
+bool build_helmholtz(const ChebOps &w, double pxi_bar, double tau, std::vector<double> &Wmat, std::vector<double> &Xmat,
+                     std::string &err);
+void ring_table(int has_l, int uniform_L, int ri /*1-based patch ring*/, int &L, int &kmax, double &off);
+
+// ---- device-side tables handed to the kernels -----------------------------------------------------------------------
+struct Timer {
+    const char *name;
+    double ms = 0.0;
+    int64_t calls = 0;
+};
+
+struct PendingEvent {
+    int timer;
+    hipEvent_t a, b;
+};
+
+}  // namespace sx
+
+struct sx_handle {
+    // geometry
+    int geom = 0, has_l = 0, has_z = 0;
+    double xmin = 0, xmax = 0, DX = 0, l_q = 2.0, zmin = 0, zmax = 0;
+    int nc = 0, V = 0, D = 0, ncoord = 1, rDim = 0, b_rDim = 0, nz = 1, Zb = 1, nsz = 1;
+    int cell0 = 0, ncells = 0, nrings = 0, nbt = 0, tile_num = 0, uniform_L = 0;
+    int kDim = 0, K2 = 1, kDim_t = 0, K2t = 1, kmax_max = 0, L_max = 1;
+    int64_t N = 0, Nh = 0, C = 0, S_patch = 0, S_tile = 0;
+    int slot[7] = {-1, -1, -1, -1, -1, -1, -1};
+    std::vector<int> hL, hkmax;
+    std::vector<double> hoff;
+    std::vector<int64_t> hpstart;
+    std::vector<int> bcl, bcl0, bcr, bcb, bct;
+    // model
+    double ts = 0;
+    int eq = SX_EQ_NONE, semi = 0, w_index = 0, xi_index = 0, col_var = 0;
+    double par[SX_NPARAMS] = {};
+    int rot = 0;   // rotation of the expdot / impdot history buffers
+    // device
+    hipStream_t stream = nullptr;
+    double *d_A = nullptr, *d_Bfull = nullptr, *d_Btile = nullptr, *d_Btile_own = nullptr;
+    const double *d_Bsrc = nullptr;
+    int64_t *d_rowoff = nullptr;
+    double *d_Az = nullptr, *d_phys = nullptr, *d_np1 = nullptr, *d_E[3] = {}, *d_I[3] = {};
+    double *d_Fl = nullptr, *d_Bz = nullptr;
+    double *d_phi = nullptr, *d_wq = nullptr;
+    int *d_L = nullptr, *d_kmax = nullptr;
+    int64_t *d_pstart = nullptr, *d_twoff = nullptr, *d_phoff = nullptr;
+    double2 *d_tw = nullptr, *d_ph = nullptr;
+    double *d_Mz = nullptr, *d_CB = nullptr, *d_MintT = nullptr, *d_MdzT = nullptr, *d_MrecT = nullptr;
+    double *d_WT[2] = {}, *d_XT[2] = {};
+    double tau[2] = {0, 0};
+    int *d_cls = nullptr, *d_cmeta = nullptr;   // cmeta [ncls][4] = nfree, periodic, rl, rr
+    double *d_gl = nullptr, *d_gr = nullptr, *d_Lband = nullptr, *d_Larrow = nullptr;
+    double *d_r = nullptr, *d_cosl = nullptr, *d_sinl = nullptr, *d_z = nullptr;
+    int *d_flag = nullptr;
+    int ncls = 0;
+    size_t dev_bytes = 0;
+    std::vector<void *> allocs;
+    // timers
+    int timers_on = 0;
+    std::vector<sx::Timer> timers;
+    std::vector<sx::PendingEvent> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace sx {
+// kernel launchers (sx_kernels.hip); each returns hipError_t from the launch
+void launch_zinv(sx_handle *h);
+void launch_rl_inverse(sx_handle *h);
+void launch_physics(sx_handle *h, int t);
+void launch_copy_slot0(sx_handle *h);
+void launch_fl_forward(sx_handle *h);
+void launch_sb(sx_handle *h);
+void launch_zf(sx_handle *h);
+void launch_solve(sx_handle *h);
+void launch_halo_add(sx_handle *h, const double *recv);
+void launch_nan_check(sx_handle *h);
+int timer_id(sx_handle *h, const char *name);
+void timer_begin(sx_handle *h, int id);
+void timer_end(sx_handle *h);
+void timers_flush(sx_handle *h);
+void set_error(const std::string &msg);
+}  // namespace sx

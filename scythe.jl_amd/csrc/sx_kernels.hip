@@ -1,0 +1,699 @@
+// HIP kernels (gfx950) for the Scythe.jl spectral-transform time-stepping path.
+//
+// Device data layout:
+//   spectral   A, B     [radial node m][col]            col = (v * Zb + zm) * K2 + blk   (blk fastest)
+//   Az                  [tile node j][v][sz][z][blk]    sz = value, d/dz, d2/dz2 (z already inverted)
+//   physical            [slot][v][point]                point = (pstart[ring] + l) * nz + z   (reference layout)
+//   var_np1, expdot_*   [v][point]
+//   Fl                  [ring][v][z][blk]               ring spectra of var_np1
+//   Bz                  [tile node j][v][z][blk]        radial inner products before the vertical transform
+// The radial node is the slowest index of every spectral array so that (a) the banded solve runs one lane per
+// right-hand side with perfectly coalesced rows, (b) radial evaluation / inner products stream whole rows,
+// (c) a tile's halo (3 nodes) is one contiguous block.
+#include "sx_internal.hpp"
+#include <cmath>
+
+namespace sx {
+
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) set_error(std::string(#x) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+constexpr int ZC = 16;   // z-levels per workgroup in the ring kernels: 16 * 8 B = one 128-B line per (ring point)
+
+// ------------------------------------------------------------------------------------------------ vertical inverse
+// Az[j][v][sz][z][blk] = sum_zm Mz[v][sz][z][zm] * A[(cell0 + j)][v][zm][blk]
+__global__ void k_zinv(const double *__restrict__ A, double *__restrict__ Az, const double *__restrict__ Mz,
+                       int V, int nz, int Zb, int K2, int64_t C, int cell0) {
+    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;              // (v, sz, z)
+    const int j = blockIdx.z;
+    const int z = q % nz, sz = (q / nz) % 3, v = q / (3 * nz);
+    if (blk >= K2) return;
+    const double *a = A + (int64_t)(cell0 + j) * C + (int64_t)v * Zb * K2 + blk;
+    const double *m = Mz + (((int64_t)v * 3 + sz) * nz + z) * Zb;
+    double s = 0.0;
+    for (int zm = 0; zm < Zb; zm++) s += m[zm] * a[(int64_t)zm * K2];
+    Az[((((int64_t)j * V + v) * 3 + sz) * nz + z) * K2 + blk] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ radial + azimuthal inverse
+// One workgroup per (z-chunk, variable, ring): radial evaluation (4 rows of Az), phase reference, truncated inverse
+// DFT with lambda-derivatives, stores straight into the reference physical layout (z innermost => 128-B lines).
+__global__ void __launch_bounds__(256)
+k_rl_inverse(const double *__restrict__ Az, double *__restrict__ phys, const double *__restrict__ phi,
+             const int *__restrict__ Lr, const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart,
+             const int64_t *__restrict__ twoff, const double2 *__restrict__ tw, const int64_t *__restrict__ phoff,
+             const double2 *__restrict__ ph, int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
+             int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz, int has_l, int cstride) {
+    extern __shared__ double sm[];
+    const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * ZC;
+    const int zc = min(ZC, nz - z0);
+    const int L = Lr[ring], km = has_l ? kmaxr[ring] : 0;
+    const int j0 = ring / MUBAR;
+    double *cR = sm, *cI = sm + (size_t)ZC * cstride;
+    const double2 *twr = tw + twoff[ring];
+    const double2 *phr = ph + phoff[ring];
+    const int64_t p0 = pstart[ring];
+    const int tid = threadIdx.x;
+
+    for (int q = 0; q < 5; q++) {
+        // coefficient line q: (sz, d) = (0,0) (0,1) (0,2) (1,0) (2,0)
+        const int sz = q < 3 ? 0 : q - 2, d = q < 3 ? q : 0;
+        if (sz >= nsz) break;
+        const int slot0 = (q == 0) ? s_u : (q == 1) ? s_r : (q == 2) ? s_rr : (q == 3) ? s_z : s_zz;
+        const double *p = phi + ((int64_t)d * nrings + ring) * 4;
+        const double f0 = p[0], f1 = p[1], f2 = p[2], f3 = p[3];
+        __syncthreads();
+        for (int e = tid; e < zc * (km + 1); e += blockDim.x) {
+            const int k = e % (km + 1), zz = e / (km + 1);
+            const double *a = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + zz)) * K2;
+            double cr, ci = 0.0;
+            if (k == 0) {
+                cr = f0 * a[0] + f1 * a[azrow] + f2 * a[2 * azrow] + f3 * a[3 * azrow];
+            } else {
+                const int b = 2 * k - 1;
+                cr = f0 * a[b] + f1 * a[azrow + b] + f2 * a[2 * azrow + b] + f3 * a[3 * azrow + b];
+                ci = f0 * a[b + 1] + f1 * a[azrow + b + 1] + f2 * a[2 * azrow + b + 1] + f3 * a[3 * azrow + b + 1];
+                const double2 w = phr[k];          // e^{+i k off}
+                const double tr = cr * w.x - ci * w.y;
+                ci = cr * w.y + ci * w.x;
+                cr = 2.0 * tr;
+                ci = 2.0 * ci;
+            }
+            cR[zz * cstride + k] = cr;
+            cI[zz * cstride + k] = ci;
+        }
+        __syncthreads();
+        const bool lamder = (q == 0) && has_l;
+        for (int o = tid; o < L * zc; o += blockDim.x) {
+            const int zz = o % zc, l = o / zc;
+            const double *r = cR + zz * cstride, *im = cI + zz * cstride;
+            double a0 = r[0], a1 = 0.0, a2 = 0.0;
+            int idx = 0;
+            for (int k = 1; k <= km; k++) {
+                idx += l;
+                if (idx >= L) idx -= L;
+                const double2 t = twr[idx];
+                const double val = r[k] * t.x - im[k] * t.y;
+                a0 += val;
+                if (lamder) {
+                    a1 -= k * (im[k] * t.x + r[k] * t.y);
+                    a2 -= (double)k * k * val;
+                }
+            }
+            const int64_t pt = (p0 + l) * nz + z0 + zz;
+            phys[((int64_t)slot0 * V + v) * N + pt] = a0;
+            if (lamder) {
+                phys[((int64_t)s_l * V + v) * N + pt] = a1;
+                phys[((int64_t)s_ll * V + v) * N + pt] = a2;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward azimuthal
+// Fl[ring][v][z][blk] = (1/L) sum_l var_np1[v][(pstart + l) nz + z] e^{-ik lambda_l}
+__global__ void __launch_bounds__(256)
+k_fl_forward(const double *__restrict__ np1, double *__restrict__ Fl, const int *__restrict__ Lr,
+             const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
+             const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
+             int nz, int K2, int64_t N, int has_l, int xstride) {
+    extern __shared__ double sm[];
+    const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * ZC;
+    const int zc = min(ZC, nz - z0);
+    const int L = Lr[ring], km = has_l ? kmaxr[ring] : 0;
+    const double2 *twr = tw + twoff[ring];
+    const double2 *phr = ph + phoff[ring];
+    const int64_t p0 = pstart[ring];
+    const int tid = threadIdx.x;
+    for (int o = tid; o < L * zc; o += blockDim.x) {
+        const int zz = o % zc, l = o / zc;
+        sm[zz * xstride + l] = np1[(int64_t)v * N + (p0 + l) * nz + z0 + zz];
+    }
+    __syncthreads();
+    const double inv = 1.0 / L;
+    for (int e = tid; e < zc * (km + 1); e += blockDim.x) {
+        const int k = e % (km + 1), zz = e / (km + 1);
+        const double *x = sm + zz * xstride;
+        double sr = 0.0, si = 0.0;
+        int idx = 0;
+        for (int l = 0; l < L; l++) {
+            const double2 t = twr[idx];
+            sr += x[l] * t.x;
+            si -= x[l] * t.y;
+            idx += k;
+            if (idx >= L) idx -= L;
+        }
+        double *out = Fl + (((int64_t)ring * V + v) * nz + z0 + zz) * K2;
+        if (k == 0) {
+            out[0] = sr * inv;
+        } else {
+            const double2 w = phr[k];              // multiply by e^{-i k off}
+            out[2 * k - 1] = (sr * w.x + si * w.y) * inv;
+            out[2 * k] = (si * w.x - sr * w.y) * inv;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ radial inner products
+// Bz[j][e] = sum over the rings of cells j-3..j of wq * phi0 * Fl[ring][e],   e = (v, z, blk) flattened
+__global__ void k_sb(const double *__restrict__ Fl, double *__restrict__ Bz, const double *__restrict__ phi,
+                     const double *__restrict__ wq, int ncells, int64_t plane) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (e >= plane) return;
+    double s = 0.0;
+    for (int c = max(0, j - 3); c <= min(ncells - 1, j); c++) {
+        const int jj = j - c;
+        for (int mu = 0; mu < MUBAR; mu++) {
+            const int ring = c * MUBAR + mu;
+            s += wq[ring] * phi[(int64_t)ring * 4 + jj] * Fl[(int64_t)ring * plane + e];
+        }
+    }
+    Bz[(int64_t)j * plane + e] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ vertical forward
+// B[j][v][zm][blk] = sum_z CB[zm][z] Bz[j][v][z][blk]
+__global__ void k_zf(const double *__restrict__ Bz, double *__restrict__ B, const double *__restrict__ CB, int V, int nz,
+                     int Zb, int K2) {
+    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = blockIdx.y;       // (v, zm)
+    const int j = blockIdx.z;
+    const int zm = q % Zb, v = q / Zb;
+    if (blk >= K2) return;
+    const double *x = Bz + (((int64_t)j * V + v) * nz) * K2 + blk;
+    const double *c = CB + (int64_t)zm * nz;
+    double s = 0.0;
+    for (int z = 0; z < nz; z++) s += c[z] * x[(int64_t)z * K2];
+    B[(int64_t)j * V * Zb * K2 + ((int64_t)v * Zb + zm) * K2 + blk] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ B -> A banded SPD solve
+// One lane per right-hand side (column); rows are contiguous across lanes so every load/store is coalesced.
+// a = Gamma^T (L L^T)^-1 Gamma b with L banded (half-bandwidth 3) plus, for PERIODIC, three dense last rows.
+__global__ void __launch_bounds__(256)
+k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, double *__restrict__ A,
+        const int *__restrict__ cls, const int *__restrict__ cmeta, const double *__restrict__ gl,
+        const double *__restrict__ gr, const double *__restrict__ Lband, const double *__restrict__ Larrow, int nb,
+        int Zb, int K2, int64_t C) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= C) return;
+    const int blk = (int)(col % K2);
+    const int v = (int)(col / ((int64_t)Zb * K2));
+    const int c = cls[v * 2 + (blk == 0 ? 0 : 1)];
+    const int n = cmeta[c * 4 + 0], per = cmeta[c * 4 + 1], rl = cmeta[c * 4 + 2], rr = cmeta[c * 4 + 3];
+    const double *Lb = Lband + (int64_t)c * nb * 4;
+    const double *La = Larrow + (int64_t)c * 3 * nb;
+    const double *g_l = gl + c * 6, *g_r = gr + c * 6;
+#define BROW(m) Bsrc[rowoff[m] + col]
+#define AROW(m) A[(int64_t)(m) * C + col]
+    if (!per) {
+        // forward substitution; the free unknown i lives in row rl + i of A
+        double y1 = 0.0, y2 = 0.0, y3 = 0.0;     // y[i-1], y[i-2], y[i-3]
+        for (int i = 0; i < n; i++) {
+            double s = BROW(rl + i);
+            if (i < 2) for (int q = 0; q < rl; q++) s += g_l[q * 2 + i] * BROW(q);
+            if (i >= n - 2) for (int q = 0; q < rr; q++) s += g_r[q * 2 + (n - 1 - i)] * BROW(nb - 1 - q);
+            const double *l = Lb + (int64_t)i * 4;
+            s -= l[2] * y1 + l[1] * y2 + l[0] * y3;
+            s /= l[3];
+            y3 = y2; y2 = y1; y1 = s;
+            AROW(rl + i) = s;
+        }
+        // back substitution
+        double x1 = 0.0, x2 = 0.0, x3 = 0.0;     // x[i+1], x[i+2], x[i+3]
+        double xl0 = 0.0, xl1 = 0.0, xr0 = 0.0, xr1 = 0.0;
+        for (int i = n - 1; i >= 0; i--) {
+            double s = AROW(rl + i);
+            if (i + 1 < n) s -= Lb[(int64_t)(i + 1) * 4 + 2] * x1;
+            if (i + 2 < n) s -= Lb[(int64_t)(i + 2) * 4 + 1] * x2;
+            if (i + 3 < n) s -= Lb[(int64_t)(i + 3) * 4 + 0] * x3;
+            s /= Lb[(int64_t)i * 4 + 3];
+            x3 = x2; x2 = x1; x1 = s;
+            AROW(rl + i) = s;
+            if (i == n - 1) xr0 = s;
+            if (i == n - 2) xr1 = s;
+            if (i == 1) xl1 = s;
+            if (i == 0) xl0 = s;
+        }
+        for (int q = 0; q < rl; q++) AROW(q) = g_l[q * 2] * xl0 + g_l[q * 2 + 1] * xl1;
+        for (int q = 0; q < rr; q++) AROW(nb - 1 - q) = g_r[q * 2] * xr0 + g_r[q * 2 + 1] * xr1;
+    } else {
+        // periodic: unknown i <-> row i + 1; rows 0, nb-2, nb-1 fold onto unknowns n-1, 0, 1
+        double y1 = 0.0, y2 = 0.0, y3 = 0.0;
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;        // arrow-row dot products
+        for (int i = 0; i < n - 3; i++) {
+            double s = BROW(i + 1);
+            if (i == 0) s += BROW(nb - 2);
+            if (i == 1) s += BROW(nb - 1);
+            const double *l = Lb + (int64_t)i * 4;
+            s -= l[2] * y1 + l[1] * y2 + l[0] * y3;
+            s /= l[3];
+            y3 = y2; y2 = y1; y1 = s;
+            AROW(i + 1) = s;
+            acc0 += La[i] * s;
+            acc1 += La[nb + i] * s;
+            acc2 += La[2 * nb + i] * s;
+        }
+        double t0 = (BROW(n - 2) - acc0) / La[n - 3];
+        double t1 = (BROW(n - 1) - acc1 - La[nb + n - 3] * t0) / La[nb + n - 2];
+        double t2 = (BROW(n) + BROW(0) - acc2 - La[2 * nb + n - 3] * t0 - La[2 * nb + n - 2] * t1) / La[2 * nb + n - 1];
+        // back substitution of the dense 3x3 corner
+        const double u2 = t2 / La[2 * nb + n - 1];
+        const double u1 = (t1 - La[2 * nb + n - 2] * u2) / La[nb + n - 2];
+        const double u0 = (t0 - La[nb + n - 3] * u1 - La[2 * nb + n - 3] * u2) / La[n - 3];
+        AROW(n - 2) = u0;
+        AROW(n - 1) = u1;
+        AROW(n) = u2;
+        double x1 = 0.0, x2 = 0.0, x3 = 0.0;
+        double first0 = 0.0, first1 = 0.0;
+        for (int i = n - 4; i >= 0; i--) {
+            double s = AROW(i + 1);
+            if (i + 1 < n - 3) s -= Lb[(int64_t)(i + 1) * 4 + 2] * x1;
+            if (i + 2 < n - 3) s -= Lb[(int64_t)(i + 2) * 4 + 1] * x2;
+            if (i + 3 < n - 3) s -= Lb[(int64_t)(i + 3) * 4 + 0] * x3;
+            s -= La[i] * u0 + La[nb + i] * u1 + La[2 * nb + i] * u2;
+            s /= Lb[(int64_t)i * 4 + 3];
+            x3 = x2; x2 = x1; x1 = s;
+            AROW(i + 1) = s;
+            if (i == 0) first0 = s;
+            if (i == 1) first1 = s;
+        }
+        AROW(0) = u2;            // a_{-1} = a_{n-1}
+        AROW(nb - 2) = first0;   // a_{n}  = a_0
+        AROW(nb - 1) = first1;   // a_{n+1} = a_1
+    }
+#undef BROW
+#undef AROW
+}
+
+__global__ void k_halo_add(double *__restrict__ B, const double *__restrict__ recv, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) B[i] += recv[i];
+}
+
+__global__ void k_nan_check(const double *__restrict__ x, int64_t n, int *flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int bad = 0;
+    for (; i < n; i += stride) bad |= (x[i] != x[i]);
+    if (bad) atomicOr(flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------ equation sets
+struct PhysArgs {
+    const double *phys;   // [D][V][N]
+    double *physw;        // same array, for the diagnostic w
+    double *En;           // expdot_n  [V][N]
+    double *E1, *E2;      // expdot_nm1 / nm2 (read)
+    double *In;           // impdot_n
+    double *np1;          // var_np1
+    const double *r, *cosl, *sinl, *z;
+    const double *MintT, *MdzT;
+    int64_t N;
+    int V, nz, t, eq;
+    int s_u, s_r, s_rr, s_l, s_ll, s_z, s_zz;
+    double ts;
+    double par[SX_NPARAMS];
+};
+
+// explicit_timestep (src/semiimplicit.jl:672-698); history arrays are rotated by the host instead of copied
+__device__ __forceinline__ double ab_step(const PhysArgs &a, int v, int64_t p, double u, double en) {
+    const int64_t o = (int64_t)v * a.N + p;
+    a.En[o] = en;
+    double un;
+    if (a.t == 1) un = u + (a.ts * en);
+    else if (a.t == 2) un = u + (0.5 * a.ts) * ((3.0 * en) - a.E1[o]);
+    else un = u + ((a.ts / 12.0) * ((23.0 * en) - (16.0 * a.E1[o]) + (5.0 * a.E2[o])));
+    a.np1[o] = un;
+    return un;
+}
+
+#define PS(v, s) a.phys[((int64_t)(s) * a.V + (v)) * a.N + p]
+
+__global__ void k_phys_pointwise(PhysArgs a) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= a.N) return;
+    const double *par = a.par;
+    const double r = a.r[p / a.nz];
+    switch (a.eq) {
+        case SX_EQ_NONE:
+            for (int v = 0; v < a.V; v++) a.np1[(int64_t)v * a.N + p] = PS(v, a.s_u);
+            return;
+        case SX_EQ_LINEAR_ADVECTION_1D: {      // src/testModels.jl:15
+            const double e = -(par[SX_P_C0] * PS(0, a.s_r)) + (par[SX_P_K] * PS(0, a.s_rr));
+            ab_step(a, 0, p, PS(0, a.s_u), e);
+            for (int v = 1; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+        } break;
+        case SX_EQ_LINEAR_ADVECTION_RZ: {      // src/testModels.jl:40
+            const double hr = PS(0, a.s_r);
+            const double e = (-PS(1, a.s_u) * hr) + (-PS(3, a.s_u) * PS(0, a.s_z)) +
+                             (par[SX_P_K] * ((hr / r) + PS(0, a.s_rr) + PS(0, a.s_zz)));
+            ab_step(a, 0, p, PS(0, a.s_u), e);
+            for (int v = 1; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+        } break;
+        case SX_EQ_LINEAR_ADVECTION_RL:        // src/testModels.jl:62-68
+        case SX_EQ_LINEAR_ADVECTION_RLZ: {     // src/testModels.jl:93
+            const double hr = PS(0, a.s_r), hl = PS(0, a.s_l);
+            double e = (-PS(1, a.s_u) * hr) - (PS(2, a.s_u) * (hl / r));
+            if (a.eq == SX_EQ_LINEAR_ADVECTION_RLZ || par[SX_P_K] > 0.0)
+                e += par[SX_P_K] * ((hr / r) + PS(0, a.s_rr) + (PS(0, a.s_ll) / (r * r)));
+            ab_step(a, 0, p, PS(0, a.s_u), e);
+            for (int v = 1; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+        } break;
+        case SX_EQ_ONEWAY_SW_SLAB:             // src/shallowWaterModels.jl:60-108
+        case SX_EQ_TWOWAY_SW_SLAB: {           // src/shallowWaterModels.jl:176-228
+            const double g = par[SX_P_G], K = par[SX_P_K], Cd = par[SX_P_CD], Hfree = par[SX_P_HFREE],
+                         Hb = par[SX_P_HB], f = par[SX_P_F];
+            const double h = PS(0, a.s_u), hr = PS(0, a.s_r), hl = PS(0, a.s_l);
+            const double ug = PS(1, a.s_u), ugr = PS(1, a.s_r), ugl = PS(1, a.s_l);
+            const double vg = PS(2, a.s_u), vgr = PS(2, a.s_r), vgl = PS(2, a.s_l);
+            const double ub = PS(3, a.s_u), ubr = PS(3, a.s_r), ubrr = PS(3, a.s_rr), ubl = PS(3, a.s_l), ubll = PS(3, a.s_ll);
+            const double vb = PS(4, a.s_u), vbr = PS(4, a.s_r), vbrr = PS(4, a.s_rr), vbl = PS(4, a.s_l), vbll = PS(4, a.s_ll);
+            const double U = 0.78 * sqrt((ub * ub) + (vb * vb));
+            const double w = -Hb * ((ub / r) + ubr + (vbl / r));
+            a.physw[((int64_t)a.s_u * a.V + 5) * a.N + p] = w;
+            const double w_ = 0.5 * fabs(w) - w;
+            double e0 = ((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)));
+            if (a.eq == SX_EQ_TWOWAY_SW_SLAB) e0 += -(Hfree + h) * w * par[SX_P_S1];
+            const double e1 = ((-vg * ugl / r) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg / r)));
+            const double e2 = ((-vg * vgl / r) + (-ug * vgr)) + (-g * (hl / r)) + (-ug * (f + (vg / r)));
+            const double e3 = ((-vb * ubl / r) + (-ub * ubr)) + (-g * hr) + (vb * (f + (vb / r))) + (-(Cd * U * ub / Hb)) +
+                              (w_ * (ug - ub) / Hb) +
+                              (K * ((ubr / r) + ubrr - (ub / (r * r)) + (ubll / (r * r)) - (2.0 * vbl / (r * r))));
+            const double e4 = ((-vb * vbl / r) + (-ub * vbr)) + (-g * (hl / r)) + (-ub * (f + (vb / r))) + (-(Cd * U * vb / Hb)) +
+                              (w_ * (vg - vb) / Hb) +
+                              (K * ((vbr / r) + vbrr - (vb / (r * r)) + (vbll / (r * r)) + (2.0 * ubl / (r * r))));
+            ab_step(a, 0, p, h, e0);
+            ab_step(a, 1, p, ug, e1);
+            ab_step(a, 2, p, vg, e2);
+            ab_step(a, 3, p, ub, e3);
+            ab_step(a, 4, p, vb, e4);
+            ab_step(a, 5, p, w, 0.0);
+            for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+        } break;
+        case SX_EQ_LINEAR_ACOUSTIC_RZ: {
+            const double K = par[SX_P_K], pxi = par[SX_P_PXI_BAR];
+            const double u = PS(3, a.s_u), w = PS(4, a.s_u);
+            double e[5];
+            for (int v = 0; v < 5; v++) e[v] = (-u * PS(v, a.s_r)) + (-w * PS(v, a.s_z));
+            const double d0 = K * (PS(0, a.s_rr) + PS(0, a.s_zz)), d2 = K * (PS(2, a.s_rr) + PS(2, a.s_zz));
+            const double d3 = K * (PS(3, a.s_rr) + PS(3, a.s_zz)), d4 = K * (PS(4, a.s_rr) + PS(4, a.s_zz));
+            const double xir = PS(1, a.s_r), xiz = PS(1, a.s_z), wz = PS(4, a.s_z);
+            e[0] = e[0] + d0;
+            e[1] = e[1] - PS(3, a.s_r) - wz;
+            e[2] = e[2] + d2;
+            e[3] = e[3] + (-(pxi * xir)) + d3;
+            e[4] = e[4] + (-(pxi * xiz)) + d4;
+            for (int v = 0; v < 5; v++) {
+                ab_step(a, v, p, PS(v, a.s_u), e[v]);
+                a.In[(int64_t)v * a.N + p] = (v == 1) ? -wz : (v == 4) ? -(pxi * xiz) : 0.0;
+            }
+        } break;
+        default: break;
+    }
+}
+
+// Oneway_ShallowWater_HeightResolvedBL (src/shallowWaterModels.jl:346-511). One workgroup handles `cpb` columns;
+// thread (c, k) owns level k of column c. The three per-column Chebyshev operators (integral of the divergence,
+// derivative of the two vertical fluxes) are dense nz x nz mat-vecs with the operands staged in LDS.
+__global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgs a, int cpb) {
+    extern __shared__ double sm[];
+    const int nz = a.nz;
+    const int k = threadIdx.x % nz, cl = threadIdx.x / nz;
+    const int64_t col = (int64_t)blockIdx.x * cpb + cl;
+    const int64_t ncol = a.N / nz;
+    const bool live = (cl < cpb) && (col < ncol);
+    double *sdiv = sm, *sfu = sm + (size_t)cpb * nz, *sfv = sm + (size_t)2 * cpb * nz;
+    double *sub = sm + (size_t)3 * cpb * nz, *svb = sm + (size_t)4 * cpb * nz;
+    const double *par = a.par;
+    const double g = par[SX_P_G], Kh = par[SX_P_KH], Hfree = par[SX_P_HFREE], f = par[SX_P_F];
+    const int64_t p = live ? col * nz + k : 0;
+    double r = 1.0, h = 0, hr = 0, hl = 0, ug = 0, ugr = 0, ugl = 0, vg = 0, vgr = 0, vgl = 0;
+    double ub = 0, ubr = 0, ubrr = 0, ubl = 0, ubll = 0, ubz = 0, vb = 0, vbr = 0, vbrr = 0, vbl = 0, vbll = 0, vbz = 0;
+    if (live) {
+        r = a.r[col];
+        h = PS(0, a.s_u); hr = PS(0, a.s_r); hl = PS(0, a.s_l);
+        ug = PS(1, a.s_u); ugr = PS(1, a.s_r); ugl = PS(1, a.s_l);
+        vg = PS(2, a.s_u); vgr = PS(2, a.s_r); vgl = PS(2, a.s_l);
+        ub = PS(3, a.s_u); ubr = PS(3, a.s_r); ubrr = PS(3, a.s_rr); ubl = PS(3, a.s_l); ubll = PS(3, a.s_ll); ubz = PS(3, a.s_z);
+        vb = PS(4, a.s_u); vbr = PS(4, a.s_r); vbrr = PS(4, a.s_rr); vbl = PS(4, a.s_l); vbll = PS(4, a.s_ll); vbz = PS(4, a.s_z);
+        const double S = sqrt((ubz * ubz) + (vbz * vbz));
+        const double l = 1.0 / ((1.0 / (0.4 * a.z[k])) + (1.0 / 80.0));
+        const double Kv = (l * l) * S;
+        sdiv[cl * nz + k] = -((ub / r) + ubr + (vbl / r));
+        sfu[cl * nz + k] = Kv * ubz;
+        sfv[cl * nz + k] = Kv * vbz;
+        sub[cl * nz + k] = ub;
+        svb[cl * nz + k] = vb;
+    }
+    __syncthreads();
+    if (live && k == 0) {
+        const double Um = par[SX_P_UM], Vm = par[SX_P_VM];
+        const double cs = a.cosl[col], sn = a.sinl[col];
+        const double sfcu = (Um * cs) + (Vm * sn), sfcv = (Vm * cs) - (Um * sn);
+        const double u10 = sub[cl * nz + 1] + sfcu, v10 = svb[cl * nz + 1] + sfcv;
+        const double U10 = sqrt(u10 * u10 + v10 * v10);
+        double Cd = par[SX_P_CD];
+        if (U10 < 5.2) Cd = 1.0e-3;
+        else if (U10 < 33.6) Cd = 4.4e-4 * sqrt(U10);
+        sfu[cl * nz] = Cd * U10 * u10;
+        sfv[cl * nz] = Cd * U10 * v10;
+    }
+    __syncthreads();
+    if (!live) return;
+    double wb = 0.0, vdu = 0.0, vdv = 0.0;
+    const double *xd = sdiv + cl * nz, *xu = sfu + cl * nz, *xv = sfv + cl * nz;
+    for (int j = 0; j < nz; j++) {
+        const double mi = a.MintT[(int64_t)j * nz + k], md = a.MdzT[(int64_t)j * nz + k];
+        wb += mi * xd[j];
+        vdu += md * xu[j];
+        vdv += md * xv[j];
+    }
+    a.physw[((int64_t)a.s_u * a.V + 5) * a.N + p] = wb;
+    const double e0 = ((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)));
+    const double e1 = ((-vg * ugl / r) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg / r)));
+    const double e2 = ((-vg * vgl / r) + (-ug * vgr)) + (-g * (hl / r)) + (-ug * (f + (vg / r)));
+    const double e3 = ((-vb * ubl / r) + (-ub * ubr) + (-wb * ubz)) + (-g * hr) + (vb * (f + (vb / r))) + vdu +
+                      (Kh * ((ubr / r) + ubrr - (ub / (r * r)) + (ubll / (r * r)) - (2.0 * vbl / (r * r))));
+    const double e4 = ((-vb * vbl / r) + (-ub * vbr) + (-wb * vbz)) + (-g * (hl / r)) + (-ub * (f + (vb / r))) + vdv +
+                      (Kh * ((vbr / r) + vbrr - (vb / (r * r)) + (vbll / (r * r)) + (2.0 * ubl / (r * r))));
+    ab_step(a, 0, p, h, e0);
+    ab_step(a, 1, p, ug, e1);
+    ab_step(a, 2, p, vg, e2);
+    ab_step(a, 3, p, ub, e3);
+    ab_step(a, 4, p, vb, e4);
+    ab_step(a, 5, p, wb, 0.0);
+    for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+}
+
+// semiimplicit_adjustment (src/semiimplicit.jl:521-597), one workgroup per group of columns
+struct SemiArgs {
+    double *np1;
+    const double *In, *I1, *I2;
+    const double *MrecT, *MdzT, *WT, *XT;
+    int64_t N;
+    int nz, t, wi, xi;
+    double ts, tau, pxi;
+};
+
+__global__ void __launch_bounds__(256) k_semiimplicit(SemiArgs a, int cpb) {
+    extern __shared__ double sm[];
+    const int nz = a.nz;
+    const int k = threadIdx.x % nz, cl = threadIdx.x / nz;
+    const int64_t col = (int64_t)blockIdx.x * cpb + cl;
+    const bool live = (cl < cpb) && (col < a.N / nz);
+    double *sw = sm, *sx_ = sm + (size_t)cpb * nz, *sg = sm + (size_t)2 * cpb * nz;
+    const int64_t p = live ? col * nz + k : 0;
+    const double ts = a.ts;
+    if (live) {
+        const int vv[2] = {a.wi, a.xi};
+        double out[2];
+        for (int q = 0; q < 2; q++) {
+            const int64_t o = (int64_t)vv[q] * a.N + p;
+            double x = a.np1[o];
+            const double In = a.In[o];
+            if (a.t == 1) x = x - (ts * In) + (ts * 0.5 * In);
+            else if (a.t == 2) x = x - (0.5 * ts) * ((3.0 * In) - a.I1[o]) - (ts * In) + (ts * 0.75 * a.I1[o]);
+            else x = x - ((ts / 12.0) * ((23.0 * In) - (16.0 * a.I1[o]) + (5.0 * a.I2[o]))) - (ts * In) + (ts * 0.75 * a.I1[o]);
+            out[q] = x;
+        }
+        sw[cl * nz + k] = out[0];
+        sx_[cl * nz + k] = out[1];
+    }
+    __syncthreads();
+    double xrec = 0.0, xz = 0.0;
+    if (live) {
+        const double *x = sx_ + cl * nz;
+        for (int j = 0; j < nz; j++) {
+            xrec += a.MrecT[(int64_t)j * nz + k] * x[j];
+            xz += a.MdzT[(int64_t)j * nz + k] * x[j];
+        }
+        // g = [0; 0; (tau Pxi xi*_z - w*)[2 : nz-1]]
+        if (k >= 1 && k < nz - 1) sg[cl * nz + k + 1] = (a.tau * a.pxi * xz) - sw[cl * nz + k];
+        if (k < 2) sg[cl * nz + k] = 0.0;
+    }
+    __syncthreads();
+    if (!live) return;
+    double wn = 0.0, wz = 0.0;
+    const double *gv = sg + cl * nz;
+    for (int j = 0; j < nz; j++) {
+        wn += a.WT[(int64_t)j * nz + k] * gv[j];
+        wz += a.XT[(int64_t)j * nz + k] * gv[j];
+    }
+    a.np1[(int64_t)a.wi * a.N + p] = wn;
+    a.np1[(int64_t)a.xi * a.N + p] = xrec - (a.tau * wz);
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static inline dim3 grid1(int64_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+void launch_zinv(sx_handle *h) {
+    if (!h->has_z) return;
+    const int id = timer_id(h, "k_zinv");
+    timer_begin(h, id);
+    dim3 g((h->K2 + 255) / 256, h->V * 3 * h->nz, h->nbt);
+    hipLaunchKernelGGL(k_zinv, g, dim3(256), 0, h->stream, h->d_A, h->d_Az, h->d_Mz, h->V, h->nz, h->Zb, h->K2, h->C,
+                       h->cell0);
+    HIPCHK(hipGetLastError());
+    timer_end(h);
+}
+
+void launch_rl_inverse(sx_handle *h) {
+    const int id = timer_id(h, "k_rl_inverse");
+    timer_begin(h, id);
+    const int cstride = (h->kmax_max + 1) | 1;
+    const size_t lds = sizeof(double) * 2 * ZC * cstride;
+    const double *az = h->has_z ? h->d_Az : h->d_A + (int64_t)h->cell0 * h->C;
+    const int64_t azrow = h->has_z ? (int64_t)h->V * 3 * h->nz * h->K2 : h->C;
+    dim3 g((h->nz + ZC - 1) / ZC, h->V, h->nrings);
+    hipLaunchKernelGGL(k_rl_inverse, g, dim3(256), lds, h->stream, az, h->d_phys, h->d_phi, h->d_L, h->d_kmax, h->d_pstart,
+                       h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2, h->nrings, h->N, azrow,
+                       h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6], h->has_l, cstride);
+    HIPCHK(hipGetLastError());
+    timer_end(h);
+}
+
+static PhysArgs phys_args(sx_handle *h, int t) {
+    PhysArgs a;
+    a.phys = h->d_phys;
+    a.physw = h->d_phys;
+    a.En = h->d_E[h->rot % 3];
+    a.E1 = h->d_E[(h->rot + 1) % 3];
+    a.E2 = h->d_E[(h->rot + 2) % 3];
+    a.In = h->d_I[0] ? h->d_I[h->rot % 3] : nullptr;
+    a.np1 = h->d_np1;
+    a.r = h->d_r; a.cosl = h->d_cosl; a.sinl = h->d_sinl; a.z = h->d_z;
+    a.MintT = h->d_MintT; a.MdzT = h->d_MdzT;
+    a.N = h->N; a.V = h->V; a.nz = h->nz; a.t = t; a.eq = h->eq;
+    a.s_u = h->slot[0]; a.s_r = h->slot[1]; a.s_rr = h->slot[2]; a.s_l = h->slot[3]; a.s_ll = h->slot[4];
+    a.s_z = h->slot[5]; a.s_zz = h->slot[6];
+    a.ts = h->ts;
+    for (int i = 0; i < SX_NPARAMS; i++) a.par[i] = h->par[i];
+    return a;
+}
+
+// History rotation replaces the copies of explicit_timestep: after step t the buffer written as expdot_n becomes
+// expdot_nm1 and the previous nm1 becomes nm2. rot decreases by one (mod 3) per step.
+void launch_physics(sx_handle *h, int t) {
+    if (h->eq != SX_EQ_NONE && t == 1) h->rot = 0;
+    PhysArgs a = phys_args(h, t);
+    if (h->eq == SX_EQ_ONEWAY_SW_HRBL) {
+        const int id = timer_id(h, "k_phys_hrbl");
+        timer_begin(h, id);
+        const int cpb = h->nz >= 256 ? 1 : 256 / h->nz;
+        const int bs = cpb * h->nz;
+        const size_t lds = sizeof(double) * 5 * cpb * h->nz;
+        hipLaunchKernelGGL(k_phys_hrbl, grid1(h->Nh, cpb), dim3(bs), lds, h->stream, a, cpb);
+        HIPCHK(hipGetLastError());
+        timer_end(h);
+    } else {
+        const int id = timer_id(h, "k_phys_pointwise");
+        timer_begin(h, id);
+        hipLaunchKernelGGL(k_phys_pointwise, grid1(h->N, 256), dim3(256), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+        timer_end(h);
+    }
+    if (h->semi && h->eq != SX_EQ_NONE) {
+        const int id = timer_id(h, "k_semiimplicit");
+        timer_begin(h, id);
+        SemiArgs s;
+        s.np1 = h->d_np1;
+        s.In = h->d_I[h->rot % 3]; s.I1 = h->d_I[(h->rot + 1) % 3]; s.I2 = h->d_I[(h->rot + 2) % 3];
+        const int which = (t == 1) ? 0 : 1;
+        s.MrecT = h->d_MrecT; s.MdzT = h->d_MdzT; s.WT = h->d_WT[which]; s.XT = h->d_XT[which];
+        s.N = h->N; s.nz = h->nz; s.t = t; s.wi = h->w_index - 1; s.xi = h->xi_index - 1;
+        s.ts = h->ts; s.tau = h->tau[which]; s.pxi = h->par[SX_P_PXI_BAR];
+        const int cpb = h->nz >= 256 ? 1 : 256 / h->nz;
+        const size_t lds = sizeof(double) * 3 * cpb * h->nz;
+        hipLaunchKernelGGL(k_semiimplicit, grid1(h->Nh, cpb), dim3(cpb * h->nz), lds, h->stream, s, cpb);
+        HIPCHK(hipGetLastError());
+        timer_end(h);
+    }
+    if (h->eq != SX_EQ_NONE) h->rot = (h->rot + 2) % 3;
+}
+
+void launch_fl_forward(sx_handle *h) {
+    const int id = timer_id(h, "k_fl_forward");
+    timer_begin(h, id);
+    const int xstride = h->L_max | 1;
+    const size_t lds = sizeof(double) * ZC * xstride;
+    dim3 g((h->nz + ZC - 1) / ZC, h->V, h->nrings);
+    hipLaunchKernelGGL(k_fl_forward, g, dim3(256), lds, h->stream, h->d_np1, h->d_Fl, h->d_L, h->d_kmax, h->d_pstart,
+                       h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N, h->has_l, xstride);
+    HIPCHK(hipGetLastError());
+    timer_end(h);
+}
+
+void launch_sb(sx_handle *h) {
+    const int id = timer_id(h, "k_sb");
+    timer_begin(h, id);
+    const int64_t plane = (int64_t)h->V * h->nz * h->K2;
+    double *out = h->has_z ? h->d_Bz : h->d_Btile;
+    dim3 g((unsigned)((plane + 255) / 256), h->nbt);
+    hipLaunchKernelGGL(k_sb, g, dim3(256), 0, h->stream, h->d_Fl, out, h->d_phi, h->d_wq, h->ncells, plane);
+    HIPCHK(hipGetLastError());
+    timer_end(h);
+}
+
+void launch_zf(sx_handle *h) {
+    if (!h->has_z) return;
+    const int id = timer_id(h, "k_zf");
+    timer_begin(h, id);
+    dim3 g((h->K2 + 255) / 256, h->V * h->Zb, h->nbt);
+    hipLaunchKernelGGL(k_zf, g, dim3(256), 0, h->stream, h->d_Bz, h->d_Btile, h->d_CB, h->V, h->nz, h->Zb, h->K2);
+    HIPCHK(hipGetLastError());
+    timer_end(h);
+}
+
+void launch_solve(sx_handle *h) {
+    const int id = timer_id(h, "k_solve");
+    timer_begin(h, id);
+    hipLaunchKernelGGL(k_solve, grid1(h->C, 256), dim3(256), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_A, h->d_cls,
+                       h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Larrow, h->b_rDim, h->Zb, h->K2, h->C);
+    HIPCHK(hipGetLastError());
+    timer_end(h);
+}
+
+void launch_halo_add(sx_handle *h, const double *recv) {
+    const int id = timer_id(h, "k_halo_add");
+    timer_begin(h, id);
+    const int64_t n = 3 * h->C;
+    hipLaunchKernelGGL(k_halo_add, grid1(n, 256), dim3(256), 0, h->stream, h->d_Btile, recv, n);
+    HIPCHK(hipGetLastError());
+    timer_end(h);
+}
+
+void launch_nan_check(sx_handle *h) {
+    HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
+    const int64_t n = (int64_t)h->V * h->N;     // slot of the values is a contiguous [V][N] block
+    hipLaunchKernelGGL(k_nan_check, dim3(2048), dim3(256), 0, h->stream, h->d_phys + (int64_t)h->slot[0] * h->V * h->N, n,
+                       h->d_flag);
+    HIPCHK(hipGetLastError());
+}
+
+}  // namespace sx

@@ -1,0 +1,214 @@
+"""Step driver: the master / worker protocol of src/semiimplicit.jl:126-332 with one radial tile per GPU.
+
+The reference runs one Julia worker per tile, a unidirectional RemoteChannel chain for the 3-coefficient halo
+(src/semiimplicit.jl:203-219, 320-329), a SharedArray for the patch-level sum (:229, :272-282) and a redundant
+patch solve on every worker (:285).  Here a tile is a libscythe_hip handle and the exchange is done on device
+buffers: halo rows by point-to-point send/recv, owned rows by an in-place all-gather, both over
+torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""
+import os
+import time
+
+import numpy as np
+
+from .model import (Grid, GridParameters, ModelParameters, calcTileSizes, checkCFL, getGridpoints)
+
+
+class PatchLayout:
+    """Which patch rows (radial nodes) each tile computes, owns and sends (calcPatchMap / calcHaloMap,
+    src/semiimplicit.jl:79-86), and where they sit in the all-gather buffer."""
+
+    def __init__(self, patch: GridParameters, num_tiles: int, n_cols: int = 0):
+        ts = calcTileSizes(patch, num_tiles)
+        self.num_tiles = num_tiles
+        self.ncells = [int(ts[2, t]) for t in range(num_tiles)]
+        self.cell0 = [int(ts[3, t]) - 1 for t in range(num_tiles)]
+        self.tile_sizes = ts
+        self.b_rDim = patch.num_cells + 3
+        self.max_rows = max(self.ncells) + 3
+        self.n_cols = n_cols
+
+    def rows(self, t):
+        return self.ncells[t] + 3
+
+    def owned_rows(self, t):
+        return self.ncells[t] + (3 if t == self.num_tiles - 1 else 0)
+
+    def row_offsets(self, n_cols=None):
+        """Element offset of patch row m inside the [num_tiles][max_rows][n_cols] gather buffer."""
+        n_cols = n_cols or self.n_cols
+        off = np.zeros(self.b_rDim, dtype=np.int64)
+        for t in range(self.num_tiles):
+            for j in range(self.owned_rows(t)):
+                off[self.cell0[t] + j] = (t * self.max_rows + j) * n_cols
+        return off
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class LocalExchange:
+    """All tiles live in this process on one device (used by single-GPU tests of the tile protocol)."""
+
+    def __init__(self, layout: PatchLayout, tiles, device):
+        torch = _torch()
+        self.layout, self.tiles = layout, tiles
+        C = tiles[0].n_cols
+        self.buf = torch.zeros((layout.num_tiles, layout.max_rows, C), dtype=torch.float64, device=device)
+        ro = layout.row_offsets(C)
+        for t, g in enumerate(tiles):
+            g.bind_tile_b(self.buf[t].data_ptr())
+            g.bind_patch_b(self.buf.data_ptr(), ro)
+
+    def exchange(self):
+        lay = self.layout
+        for t in range(1, lay.num_tiles):
+            n = lay.ncells[t - 1]
+            self.tiles[t].halo_add(self.buf[t - 1, n:n + 3].data_ptr())
+
+
+class DistExchange:
+    """One tile per rank. Halo rows travel rank -> rank + 1, owned rows are all-gathered in place."""
+
+    def __init__(self, layout: PatchLayout, tile: Grid, device, group=None):
+        torch = _torch()
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        assert self.world == layout.num_tiles
+        self.layout, self.tile = layout, tile
+        C = tile.n_cols if tile is not None else layout.n_cols
+        self.buf = torch.zeros((self.world, layout.max_rows, C), dtype=torch.float64, device=device)
+        self.halo = torch.zeros((3, C), dtype=torch.float64, device=device)
+        if tile is not None:
+            tile.bind_tile_b(self.buf[self.rank].data_ptr())
+            tile.bind_patch_b(self.buf.data_ptr(), layout.row_offsets(C))
+
+    def my_rows(self):
+        return self.buf[self.rank]
+
+    def exchange(self, halo_add=None):
+        """halo_add(recv_tensor) adds the received rows into rows 0..2 of this tile (device kernel on the GPU path)."""
+        dist, r, W = self.dist, self.rank, self.world
+        if W > 1:
+            ops = []
+            n = self.layout.ncells[r]
+            if r < W - 1:
+                ops.append(dist.P2POp(dist.isend, self.buf[r, n:n + 3], r + 1, self.group))
+            if r > 0:
+                ops.append(dist.P2POp(dist.irecv, self.halo, r - 1, self.group))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            if r > 0:
+                if halo_add is not None:
+                    halo_add(self.halo)
+                else:
+                    self.tile.halo_add(self.halo.data_ptr())
+            dist.all_gather_into_tensor(self.buf.view(-1), self.buf[r].reshape(-1), group=self.group)
+
+
+class ModelRun:
+    """initialize_model + run_model state for one process (src/semiimplicit.jl:126-256)."""
+
+    def __init__(self, model: ModelParameters, num_tiles=1, rank=None, device=None, use_dist=False):
+        self.model = model
+        patch = model.grid_params
+        self.patch = patch
+        self.num_tiles = num_tiles
+        self.layout = PatchLayout(patch, num_tiles)
+        self.use_dist = use_dist
+        if use_dist:
+            t = rank
+            self.tiles = [Grid(patch, model, self.layout.cell0[t], self.layout.ncells[t], t + 2)]
+            self.tile_ids = [t]
+        else:
+            self.tiles = [Grid(patch, model, self.layout.cell0[t], self.layout.ncells[t], t + 2)
+                          for t in range(num_tiles)]
+            self.tile_ids = list(range(num_tiles))
+        self.exchange = None
+        if num_tiles > 1:
+            if use_dist:
+                self.exchange = DistExchange(self.layout, self.tiles[0], device)
+            else:
+                self.exchange = LocalExchange(self.layout, self.tiles, device)
+        self.t = 0
+
+    def tile_points(self, t):
+        return self.tiles[self.tile_ids.index(t)].N
+
+    def set_initial_conditions(self, values_by_tile):
+        """read_physical_grid + spectralTransform!(patch) + first splineTransform! (:134-136, :233-237)."""
+        for g, v in zip(self.tiles, values_by_tile):
+            g.set_physical_values(v)
+            g.spectralTransform_()
+        self._exchange_and_solve()
+
+    def _exchange_and_solve(self):
+        if self.exchange is not None:
+            self.exchange.exchange()
+        for g in self.tiles:
+            g.splineTransform_()
+
+    def step(self):
+        """One pass of model_loop's body (src/semiimplicit.jl:268-297) without the output branch."""
+        self.t += 1
+        for g in self.tiles:
+            g.advance(self.t)
+        self._exchange_and_solve()
+
+    def physical(self):
+        """tileTransform! on every local tile; returns the concatenated physical array."""
+        out = []
+        for g in self.tiles:
+            g.tileTransform_()
+            out.append(g.physical)
+        return np.concatenate(out, axis=0)
+
+    def synchronize(self):
+        for g in self.tiles:
+            g.synchronize()
+
+    def close(self):
+        for g in self.tiles:
+            g.close()
+
+
+def integrate_model(model: ModelParameters, num_tiles=1, verbose=False):
+    """integrate_model(model) (src/Scythe.jl:37-62) on one GPU: initial conditions from CSV, time loop with
+    output every output_interval, final output. Returns True like run_model."""
+    from .io import read_physical_grid, write_output
+    if not os.path.isdir(model.output_dir):
+        os.makedirs(model.output_dir, exist_ok=True)
+    log = open(os.path.join(model.output_dir, "scythe_out.log"), "w")
+    device = None
+    if num_tiles > 1:
+        device = "cuda"
+    run = ModelRun(model, num_tiles=num_tiles, device=device)
+    print("Initializing with %d workers and tiles" % num_tiles, file=log)
+    vals = read_physical_grid(model.initial_conditions, model.grid_params, run)
+    run.set_initial_conditions(vals)
+    num_ts = int(round(model.integration_time / model.ts))
+    output_int = int(round(model.output_interval / model.ts))
+    print("Integrating %s sec increments for %d timesteps" % (model.ts, num_ts), file=log)
+    write_output(run, model, 0.0)
+    t0 = time.time()
+    for t in range(1, num_ts + 1):
+        if verbose:
+            print("ts: %s" % (t * model.ts), file=log)
+        run.step()
+        if output_int > 0 and t % output_int == 0 and t != num_ts:
+            for g in run.tiles:
+                g.tileTransform_()
+                checkCFL(g)
+            write_output(run, model, t * model.ts)
+    print("%.6f seconds" % (time.time() - t0), file=log)
+    for g in run.tiles:
+        g.tileTransform_()
+        checkCFL(g)
+    write_output(run, model, model.integration_time)
+    print("Model complete!", file=log)
+    log.close()
+    run.close()
+    return True

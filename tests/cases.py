@@ -1,0 +1,193 @@
+"""Shared test cases: one description drives the CPU oracle (oracle/) and the HIP path (scythe.jl_amd)."""
+import numpy as np
+
+from oracle import oracle_np as O
+from oracle import oracle_c as OC
+
+VARS6 = {"h": 1, "u": 2, "v": 3, "ub": 4, "vb": 5, "wb": 6}
+BCL6 = {"h": "R1T1", "u": "R1T0", "v": "R1T0", "ub": "R1T0", "vb": "R1T0", "wb": "R1T1"}   # models/cha_bell2024
+BCR6 = {"h": "R0", "u": "R1T1", "v": "R0", "ub": "R1T1", "vb": "R0", "wb": "R0"}
+SW_PAR = dict(g=9.81, K=5000.0, Cd=2.4e-3, Hfree=2000.0, Hb=1000.0, f=5.0e-5, S1=1.0e-4, Kh=5000.0, Um=2.0, Vm=-1.0)
+
+
+def _vortex(r):
+    Rmax, V0 = 5.0e4, 50.0 / 5.0e4
+    return np.where(r < Rmax, V0 * r, Rmax * Rmax * V0 / np.maximum(r, 1.0))
+
+
+def kat_r(num_cells=100):
+    """models/LinearAdvection1D.jl with the notebook's initial condition."""
+    return dict(name="kat_r", grid=dict(geometry="R", xmin=-50.0, xmax=50.0, num_cells=num_cells, vars={"u": 1},
+                                        BCL={"u": "PERIODIC"}, BCR={"u": "PERIODIC"}),
+                eq="LinearAdvection1D", ts=0.05, par=dict(c_0=1.0, K=0.0),
+                ic=lambda p: np.exp(-(p[:, 0] / 20.0) ** 2)[:, None])
+
+
+def r_bcs(bcl="R1T0", bcr="R1T1", num_cells=24):
+    return dict(name="r_%s_%s" % (bcl, bcr), grid=dict(geometry="R", xmin=0.0, xmax=12.0, num_cells=num_cells, vars={"u": 1},
+                                                      BCL={"u": bcl}, BCR={"u": bcr}),
+                eq="LinearAdvection1D", ts=0.01, par=dict(c_0=0.5, K=0.02),
+                ic=lambda p: (np.sin(np.pi * p[:, 0] / 12.0) ** 2 * np.exp(-((p[:, 0] - 5.0) / 2.0) ** 2))[:, None])
+
+
+def rz_advection(num_cells=10, zDim=14):
+    def ic(p):
+        r, z = p[:, 0], p[:, 1]
+        b = np.exp(-((r - 5.0e3) / 2.0e3) ** 2 - ((z - 4.0e3) / 2.5e3) ** 2)
+        return np.stack([b, 2.0 + 0.0 * r, 0.0 * r, 0.5 * np.sin(np.pi * z / 1.0e4)], axis=1)
+    return dict(name="rz_adv", grid=dict(geometry="RZ", xmin=0.0, xmax=1.0e4, num_cells=num_cells, zmin=0.0, zmax=1.0e4,
+                                         zDim=zDim, vars={"h": 1, "u": 2, "v": 3, "w": 4}, BCL={"h": "R1T1"},
+                                         BCB={"w": "R1T0"}, BCT={"w": "R1T0"}),
+                eq="LinearAdvectionRZ", ts=1.0, par=dict(K=20.0), ic=ic)
+
+
+def rz_semiimplicit(num_cells=8, zDim=12):
+    def ic(p):
+        r, z = p[:, 0], p[:, 1]
+        b = np.exp(-((r - 5.0e3) / 2.0e3) ** 2 - ((z - 5.0e3) / 2.0e3) ** 2)
+        s = np.sin(np.pi * z / 1.0e4)
+        return np.stack([b, 1.0e-3 * b, 0.5 * b, s * b, 0.5 * s * b], axis=1)
+    return dict(name="rz_semi", grid=dict(geometry="RZ", xmin=0.0, xmax=1.0e4, num_cells=num_cells, zmin=0.0, zmax=1.0e4,
+                                          zDim=zDim, b_zDim=zDim, vars={"s": 1, "xi": 2, "mu": 3, "u": 4, "w": 5},
+                                          BCB={"w": "R1T0"}, BCT={"w": "R1T0"}),
+                eq="LinearAcousticRZ", ts=2.0, par=dict(K=10.0, Pxi_bar=1.2e5), ic=ic, semiimplicit=True)
+
+
+def rl_advection(num_cells=8, ring_L=None):
+    def ic(p):
+        r, l = p[:, 0], p[:, 1]
+        e = np.exp(-(r / 4.0) ** 2)
+        return np.stack([e * (1 + (r / 4) ** 2 * np.cos(2 * l) + (r / 4) * np.sin(l)), 0.3 + 0 * r, 0.2 * r], axis=1)
+    return dict(name="rl_adv", grid=dict(geometry="RL", xmin=0.0, xmax=10.0, num_cells=num_cells, vars={"h": 1, "u": 2, "v": 3},
+                                         ring_L=ring_L),
+                eq="LinearAdvectionRL", ts=0.01, par=dict(K=0.003), ic=ic)
+
+
+def rl_slab(num_cells=8, twoway=False, ring_L=None):
+    """models/cha_bell2024/*.jl boundary conditions and parameters on a small patch."""
+    def ic(p):
+        r, l = p[:, 0], p[:, 1]
+        vb = _vortex(r)
+        h = 100.0 * np.exp(-(r / 1.0e5) ** 2) * (1 + 0.1 * np.cos(2 * l))
+        u = 0.5 * np.sin(l) * r / 3.0e5
+        return np.stack([h, u, vb * (1 + 0.05 * np.cos(l)), 0.8 * u, 0.7 * vb, 0.0 * r], axis=1)
+    return dict(name="rl_slab", grid=dict(geometry="RL", xmin=0.0, xmax=3.0e5, num_cells=num_cells, vars=VARS6, BCL=BCL6,
+                                          BCR=BCR6, ring_L=ring_L),
+                eq="Twoway_ShallowWater_Slab" if twoway else "Oneway_ShallowWater_Slab", ts=3.0, par=dict(SW_PAR), ic=ic)
+
+
+def rlz_hrbl(num_cells=5, zDim=10, ring_L=None):
+    def ic(p):
+        r, l, z = p.T
+        vb = _vortex(r)
+        dec = 1.0 - np.exp(-(z + 50.0) / 300.0)
+        h = 100.0 * np.exp(-(r / 1.0e5) ** 2) * (1 + 0.1 * np.cos(2 * l))
+        u = 0.5 * np.sin(l) * r / 3.0e5
+        return np.stack([h, u, vb * (1 + 0.05 * np.cos(l)), (u - 2.0 * r / 3.0e5) * dec, 0.7 * vb * dec, 0.0 * r], axis=1)
+    return dict(name="rlz_hrbl", grid=dict(geometry="RLZ", xmin=0.0, xmax=3.0e5, num_cells=num_cells, vars=VARS6, BCL=BCL6,
+                                           BCR=BCR6, zmin=0.0, zmax=2000.0, zDim=zDim, ring_L=ring_L),
+                eq="Oneway_ShallowWater_HeightResolvedBL", ts=3.0, par=dict(SW_PAR), ic=ic)
+
+
+def rlz_advection(num_cells=4, zDim=9, ring_L=None):
+    def ic(p):
+        r, l, z = p.T
+        e = np.exp(-(r / 4.0) ** 2) * np.cos(0.4 * z)
+        return np.stack([e * (1 + (r / 4) * np.sin(l)), 0.3 + 0 * r, 0.2 * r], axis=1)
+    return dict(name="rlz_adv", grid=dict(geometry="RLZ", xmin=0.0, xmax=10.0, num_cells=num_cells, vars={"h": 1, "u": 2, "v": 3},
+                                          zmin=0.0, zmax=3.0, zDim=zDim, ring_L=ring_L, BCB={"h": "R1T1"}),
+                eq="LinearAdvectionRLZ", ts=0.01, par=dict(K=0.003), ic=ic)
+
+
+# ----------------------------------------------------------------------------- builders
+def oracle_grid(case):
+    g = dict(case["grid"])
+    return O.Grid(g.pop("geometry"), g.pop("xmin"), g.pop("xmax"), g.pop("num_cells"), g.pop("vars"), **g)
+
+
+def even_tiles(nc, n):
+    sizes = [nc // n + (1 if t < nc % n else 0) for t in range(n)]
+    out, c0 = [], 0
+    for s in sizes:
+        out.append((c0, s))
+        c0 += s
+    return out
+
+
+class OracleModel:
+    """C-oracle model (optionally split into tiles) started from the case's initial condition."""
+
+    def __init__(self, case, tiles=None, numpy_twin=False):
+        self.g = oracle_grid(case)
+        if numpy_twin:
+            self.m = O.Model(self.g, case["eq"], case["ts"], case["par"], tiles=tiles,
+                             semiimplicit=case.get("semiimplicit", False), pxi_bar=case["par"].get("Pxi_bar", 0.0))
+        else:
+            self.m = OC.ModelOracle(self.g, case["eq"], case["ts"], case["par"], tiles=tiles,
+                                    semiimplicit=case.get("semiimplicit", False))
+        pts = self.g.gridpoints()
+        self.pts = pts.reshape(len(pts), -1)
+        self.m.set_initial(case["ic"](self.pts))
+
+    def step(self):
+        self.m.step()
+
+    def physical(self):
+        return self.m.physical()
+
+    @property
+    def A(self):
+        return self.m.A
+
+
+def hip_params(case):
+    import scythe_jl_amd as S
+    g = dict(case["grid"])
+    ring_L = g.pop("ring_L", None)
+    gp = S.GridParameters(ring_uniform_L=ring_L or 0, **g)
+    mp = S.ModelParameters(ts=case["ts"], equation_set=case["eq"], grid_params=gp, physical_params=dict(case["par"]),
+                           options={"semiimplicit": case.get("semiimplicit", False)})
+    return gp, mp
+
+
+class HipModel:
+    """The product path: tiles are libscythe_hip handles, exchange on device buffers."""
+
+    def __init__(self, case, num_tiles=1, device="cuda"):
+        import scythe_jl_amd as S
+        self.gp, self.mp = hip_params(case)
+        self.run = S.ModelRun(self.mp, num_tiles=num_tiles, device=device)
+        vals = []
+        for g in self.run.tiles:
+            pts = S.getGridpoints(g)
+            vals.append(case["ic"](pts.reshape(len(pts), -1)))
+        self.run.set_initial_conditions(vals)
+
+    def step(self):
+        self.run.step()
+
+    def physical(self):
+        return self.run.physical()
+
+    @property
+    def A(self):
+        return self.run.tiles[0].patchSpectral
+
+
+def rel_err(a, b):
+    """max over derivative slots of max|a-b| / max|b| (per-slot scale)."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.ndim == 3:
+        return max(np.abs(a[:, :, d] - b[:, :, d]).max() / max(np.abs(b[:, :, d]).max(), 1e-300) for d in range(a.shape[2]))
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def rel_err_per_var(a, b):
+    """max over (var, slot) of max|a-b| / max|b| with the scale taken per variable and slot."""
+    worst = 0.0
+    for v in range(a.shape[1]):
+        for d in range(a.shape[2]):
+            sc = np.abs(b[:, v, d]).max()
+            if sc > 0:
+                worst = max(worst, np.abs(a[:, v, d] - b[:, v, d]).max() / sc)
+    return worst

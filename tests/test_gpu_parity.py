@@ -1,0 +1,63 @@
+"""-m gpu: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10     # north_star: fields within 1e-10 relative of the CPU reference
+
+
+def _run(case, nsteps, num_tiles=1, oracle_tiles=None):
+    hip = cases.HipModel(case, num_tiles=num_tiles)
+    orc = cases.OracleModel(case, tiles=oracle_tiles)
+    e0 = cases.rel_err(hip.A, orc.A)
+    assert e0 < TOL, "initial A coefficients differ: %g" % e0
+    for _ in range(nsteps):
+        hip.step()
+        orc.step()
+    a, b = hip.physical(), orc.physical()
+    assert np.isfinite(a).all()
+    return cases.rel_err_per_var(a, b)
+
+
+@pytest.mark.parametrize("bcl,bcr", [("R0", "R0"), ("R1T0", "R1T1"), ("R1T2", "R2T10"), ("R2T20", "R3"), ("R3", "R1T0")])
+def test_r_grid_boundary_conditions(bcl, bcr):
+    assert _run(cases.r_bcs(bcl, bcr), 20) < TOL
+
+
+def test_r_grid_periodic_kat_config_short():
+    assert _run(cases.kat_r(), 50) < TOL
+
+
+def test_rz_advection():
+    assert _run(cases.rz_advection(), 10) < TOL
+
+
+def test_rz_semiimplicit():
+    assert _run(cases.rz_semiimplicit(), 6) < TOL
+
+
+@pytest.mark.parametrize("ring_L", [None, 16])
+def test_rl_advection(ring_L):
+    assert _run(cases.rl_advection(ring_L=ring_L), 10) < TOL
+
+
+@pytest.mark.parametrize("twoway", [False, True])
+def test_rl_slab(twoway):
+    assert _run(cases.rl_slab(twoway=twoway), 5) < TOL
+
+
+@pytest.mark.parametrize("ring_L", [None, 32])
+def test_rlz_hrbl(ring_L):
+    assert _run(cases.rlz_hrbl(ring_L=ring_L), 4) < TOL
+
+
+def test_rlz_advection():
+    assert _run(cases.rlz_advection(), 6) < TOL
+
+
+@pytest.mark.parametrize("maker,ntiles", [(cases.kat_r, 2), (cases.kat_r, 3), (cases.rl_slab, 2), (cases.rlz_hrbl, 2)])
+def test_tiles_on_one_gpu_match_single_patch_oracle(maker, ntiles):
+    case = maker()
+    assert _run(case, 4, num_tiles=ntiles) < TOL
