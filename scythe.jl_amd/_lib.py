@@ -87,6 +87,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's). Import
+    # torch first so that libscythe_hip.so binds to the runtime torch (and RCCL) already use; loading two copies
+    # leaves the second one without a device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ScytheHipError(
             "libscythe_hip.so not found at %s - build it with `python -c 'import __graft_entry__ as g; g.build()'` "

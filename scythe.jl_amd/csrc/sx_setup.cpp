@@ -84,7 +84,7 @@ bool build_spline_class(int nc, double DX, double l_q, int bcl, int bcr, SplineC
         out.nfree = nc;
     }
     const int n = out.nfree;
-    if (n < 7) { err = "too few cells for the requested boundary conditions"; return false; }
+    if (n < (out.periodic ? 7 : 4)) { err = "too few cells for the requested boundary conditions"; return false; }
 
     // P + eps_q Q, 7-diagonal: Pb[mi][mj - mi + 3]
     double phi[4][MUBAR][4], w[MUBAR];

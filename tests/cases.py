@@ -183,11 +183,21 @@ def rel_err(a, b):
 
 
 def rel_err_per_var(a, b):
-    """max over (var, slot) of max|a-b| / max|b| with the scale taken per variable and slot."""
+    """max over (var, slot) of max|a-b| / scale[var, slot].
+
+    scale = max|b[:, var, slot]|, floored at gain[slot] * max|b[:, var, 0]| where gain[slot] is the largest
+    derivative-to-value ratio any variable shows in that slot: a derivative slot of a field that does not vary in
+    that direction holds only rounding noise, and that noise is proportional to the field's own magnitude times the
+    norm of the derivative operator."""
     worst = 0.0
-    for v in range(a.shape[1]):
-        for d in range(a.shape[2]):
-            sc = np.abs(b[:, v, d]).max()
+    vmax = [np.abs(b[:, v, 0]).max() for v in range(a.shape[1])]
+    for d in range(a.shape[2]):
+        gain = max((np.abs(b[:, v, d]).max() / vmax[v]) for v in range(a.shape[1]) if vmax[v] > 0)
+        for v in range(a.shape[1]):
+            sc = max(np.abs(b[:, v, d]).max(), gain * vmax[v])
+            diff = np.abs(a[:, v, d] - b[:, v, d]).max()
             if sc > 0:
-                worst = max(worst, np.abs(a[:, v, d] - b[:, v, d]).max() / sc)
+                worst = max(worst, diff / sc)
+            elif diff > 0:
+                return np.inf
     return worst

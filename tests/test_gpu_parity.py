@@ -57,7 +57,10 @@ def test_rlz_advection():
     assert _run(cases.rlz_advection(), 6) < TOL
 
 
-@pytest.mark.parametrize("maker,ntiles", [(cases.kat_r, 2), (cases.kat_r, 3), (cases.rl_slab, 2), (cases.rlz_hrbl, 2)])
-def test_tiles_on_one_gpu_match_single_patch_oracle(maker, ntiles):
-    case = maker()
+@pytest.mark.parametrize("maker,kw,ntiles", [(cases.kat_r, {}, 2), (cases.kat_r, {}, 3), (cases.rl_slab, {"num_cells": 9}, 2),
+                                             (cases.rl_slab, {"num_cells": 10}, 3), (cases.rlz_hrbl, {"num_cells": 7}, 2),
+                                             (cases.rz_semiimplicit, {"num_cells": 9}, 3)])
+def test_tiles_on_one_gpu_match_single_patch_oracle(maker, kw, ntiles):
+    """Several tile handles on one GPU, halo + gather on device buffers, against the one-patch oracle."""
+    case = maker(**kw)
     assert _run(case, 4, num_tiles=ntiles) < TOL
