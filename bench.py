@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py - model steps/sec of the RLZ 512x256x64 shallow-water configuration on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" is one pass of model_loop's body (src/semiimplicit.jl:268-297): tileTransform! -> equation set
+(Oneway_ShallowWater_HeightResolvedBL) -> explicit_timestep -> spectralTransform! -> halo/sum -> splineTransform!.
+Workload (SURVEY.md 8(d) "perf shape"): 171 radial cells -> 513 rings x 256 azimuthal points x 64 Chebyshev levels,
+6 variables, 7 derivative slots, fp64, synthetic vortex initial condition resident in HBM before the timed region.
+For N > 1 the 171 cells are split into N radial tiles, one per GPU (strong scaling), with the halo sent rank -> rank+1
+and the owned B rows all-gathered over RCCL.
+
+Prints ONE JSON line on rank 0 with the driver's contract plus "roofline" (dominant kernel, live hipEvent timing) and
+"cpu_baseline" (the C oracle "port" on a bounded radial sample of the same workload, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (num_cells, ring_L, zDim)
+    "rlz_513x256x64": (171, 256, 64),
+    "rlz_small": (24, 64, 16),
+}
+VARS6 = {"h": 1, "u": 2, "v": 3, "ub": 4, "vb": 5, "wb": 6}
+BCL6 = {"h": "R1T1", "u": "R1T0", "v": "R1T0", "ub": "R1T0", "vb": "R1T0", "wb": "R1T1"}
+BCR6 = {"h": "R0", "u": "R1T1", "v": "R0", "ub": "R1T1", "vb": "R0", "wb": "R0"}
+PAR = dict(g=9.81, Kh=5000.0, Cd=2.4e-3, Hfree=2000.0, f=5.0e-5, Um=0.0, Vm=0.0)
+TS = 3.0
+
+
+def initial_condition(pts):
+    """Rankine vortex (Rmax 50 km, Vmax 50 m/s) with a wave-2 height perturbation (notebooks/Cha_Bell_WCD2024_
+    initialization.ipynb cells 5, 10), extended in z with an Ekman-like decay of the boundary-layer winds."""
+    r, l, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    Rmax, V0 = 5.0e4, 50.0 / 5.0e4
+    vbar = np.where(r < Rmax, V0 * r, Rmax * Rmax * V0 / np.maximum(r, 1.0))
+    dec = 1.0 - np.exp(-(z + 50.0) / 300.0)
+    h = 100.0 * np.exp(-(r / 1.0e5) ** 2) * (1.0 + 0.05 * np.cos(2.0 * l))
+    u = 0.5 * np.sin(l) * r / 3.0e5
+    return np.stack([h, u, vbar * (1.0 + 0.02 * np.cos(l)), (u - 2.0 * r / 3.0e5) * dec, 0.7 * vbar * dec, 0.0 * r], axis=1)
+
+
+def grid_kwargs(workload):
+    nc, L, nz = WORKLOADS[workload]
+    return dict(geometry="RLZ", xmin=0.0, xmax=3.0e5, num_cells=nc, vars=VARS6, BCL=BCL6, BCR=BCR6, zmin=0.0, zmax=2000.0,
+                zDim=nz), L
+
+
+def cpu_baseline(workload, sample_cells, steps):
+    """Time the C oracle (oracle/scythe_oracle.c, OpenMP) on a radial sample of the workload: `sample_cells` cells
+    from the middle of the patch with the full azimuthal x vertical extent, plus the full-patch B->A solve."""
+    from oracle import oracle_np as O, oracle_c as OC
+    kw, L = grid_kwargs(workload)
+    g = O.Grid(kw.pop("geometry"), kw.pop("xmin"), kw.pop("xmax"), kw.pop("num_cells"), kw.pop("vars"), ring_L=L, **kw)
+    c0 = (g.nc - sample_cells) // 2
+    m = OC.ModelOracle(g, "Oneway_ShallowWater_HeightResolvedBL", TS, PAR, tiles=[(c0, sample_cells)])
+    tl = m.tiles[0]
+    m.A = np.zeros((g.S_patch(), g.V), order="F")
+    shared = np.zeros((g.S_patch(), g.V), order="F")
+    tl.add_to_shared(tl.forward(initial_condition(tl.pts)), shared)
+    m.A = tl.spline_solve(shared)
+    m.step()                                    # warm-up (page faults, thread pool)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.step()
+    dt = (time.perf_counter() - t0) / steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tl.spline_solve(shared)                 # the full-patch B->A solve is not proportional to the sample
+    dt_solve = (time.perf_counter() - t0) / steps
+    scale = g.nc / sample_cells
+    full = (dt - dt_solve) * scale + dt_solve
+    return {"value": 1.0 / full, "unit": "steps/s", "cores": OC.lib().orc_num_threads(), "kind": "port",
+            "sample": "%d of %d radial cells (%d rings x %d x %d points, %d vars), %d timed steps: %.3f s/step on the "
+                      "sample of which %.3f s is the full-patch solve; full step = (%.3f - %.3f) * %d/%d + %.3f s"
+                      % (sample_cells, g.nc, 3 * sample_cells, L, g.zDim, g.V, steps, dt, dt_solve, dt, dt_solve, g.nc,
+                         sample_cells, dt_solve)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="rlz_513x256x64", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=int, default=18)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    import torch
+    import scythe_jl_amd as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    kw, L = grid_kwargs(args.workload)
+    gp = S.GridParameters(ring_uniform_L=L, **kw)
+    mp = S.ModelParameters(ts=TS, equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
+                           physical_params=dict(PAR))
+    run = S.ModelRun(mp, num_tiles=world, rank=rank, device=torch.device("cuda", local_rank), use_dist=world > 1)
+    tile = run.tiles[0]
+    pts = S.getGridpoints(tile)
+    run.set_initial_conditions([initial_condition(pts)])
+    del pts
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run.step()
+    barrier()
+    tile.enable_timers(True)
+    tile.reset_timers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timers = tile.timers()
+    tile.enable_timers(False)
+    nan = tile.check_nan()
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        # dominant kernel by accumulated device time
+        name, (ms, calls) = max(timers.items(), key=lambda kv: kv[1][0])
+        avg_ms = ms / max(calls, 1)
+        bytes_per_launch = tile.kernel_bytes(name)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        nc, _, nz = WORKLOADS[args.workload]
+        out = {
+            "metric": "model steps/sec, RLZ 512x256x64 shallow-water",
+            "value": args.steps / elapsed,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "RLZ %dx%dx%d (rings x azimuth x levels), 6 vars, 7 derivative slots, "
+                                   "Oneway_ShallowWater_HeightResolvedBL, uniform ring table kmax<=%d, b_zDim %d"
+                                   % (3 * nc, L, nz, L // 2 - 1, int(tile.dims.b_zDim)),
+                       "num_cells": nc, "tiles": world, "ts": TS, "nan": bool(nan)},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_cells, args.cpu_steps)
+            except Exception as e:   # the baseline is a reported side figure; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    run.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -283,11 +283,15 @@ class Grid:
         self.ringstart = np.concatenate([[0], np.cumsum(self.L)])
         self.kDim = int(self.kmax.max())
         self.K2 = 1 + 2 * self.kDim
-        self.rings = [Ring(self.L[r], self.kmax[r], self.off[r]) for r in range(self.rDim)]
+        self._rings = {}
         self._spl = {}
         self._cheb = {}
 
     # -- helpers
+    @property
+    def rings(self):
+        return _LazyRings(self)
+
     def spline(self, bcl, bcr):
         key = (bcl, bcr)
         if key not in self._spl:
@@ -328,7 +332,7 @@ class Grid:
                 for z in range(self.zDim):
                     row = [r[i]]
                     if self.has_l:
-                        row.append(self.rings[ring].lam[l])
+                        row.append(self.off[ring] + 2.0 * np.pi * l / self.L[ring])
                     if self.has_z:
                         row.append(zc[z])
                     cols.append(row)
@@ -421,6 +425,19 @@ class Grid:
                         else:
                             phys[sel, vi, sl[sname]] = f.T.reshape(-1)
         return phys
+
+
+class _LazyRings:
+    """Dense ring operators are built on first use (the C oracle never needs them)."""
+
+    def __init__(self, grid):
+        self.g = grid
+
+    def __getitem__(self, r):
+        g = self.g
+        if r not in g._rings:
+            g._rings[r] = Ring(g.L[r], g.kmax[r], g.off[r])
+        return g._rings[r]
 
 
 # ----------------------------------------------------------------------------- time stepping
