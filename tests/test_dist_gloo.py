@@ -1,0 +1,93 @@
+"""CPU-only, world_size 2 (gloo): the rank -> rank+1 halo and the in-place all-gather of owned B rows assemble
+exactly the patch-level sum the reference builds in its SharedArray (src/semiimplicit.jl:320-329, 272-285)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import scythe_jl_amd as S
+from oracle import oracle_c as OC
+from tests import cases
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _to_rows(g, btile, K2t, nbt):
+    """reference tile layout [S_tile, V] -> device layout [rows][cols], col = (v * Zb + zm) * K2 + blk."""
+    out = np.zeros((nbt, g.V * g.b_zDim * g.K2))
+    for v in range(g.V):
+        b = btile[:, v].reshape(g.b_zDim, K2t, nbt)
+        for zm in range(g.b_zDim):
+            for blk in range(K2t):
+                out[:, (v * g.b_zDim + zm) * g.K2 + blk] = b[zm, blk]
+    return out
+
+
+def _patch_rows(g, shared):
+    out = np.zeros((g.b_rDim, g.V * g.b_zDim * g.K2))
+    for v in range(g.V):
+        out[:, v * g.b_zDim * g.K2:(v + 1) * g.b_zDim * g.K2] = shared[:, v].reshape(g.b_zDim * g.K2, g.b_rDim).T
+    return out
+
+
+def _worker(rank, world, port, case_name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = getattr(cases, case_name)(num_cells=9)
+        gp, _ = cases.hip_params(case)
+        g = cases.oracle_grid(case)
+        n_cols = g.V * g.b_zDim * g.K2
+        lay = S.PatchLayout(gp, world, n_cols=n_cols)
+        pts = g.gridpoints().reshape(-1, 1 + g.has_l + g.has_z)
+        vals = case["ic"](pts)
+        # expected: the reference's shared-array protocol over all tiles (oracle)
+        shared = np.zeros((g.S_patch(), g.V), order="F")
+        mine = None
+        p0 = 0
+        for t in range(world):
+            tl = OC.TileOracle(g, lay.cell0[t], lay.ncells[t])
+            b = tl.forward(vals[p0:p0 + tl.N])
+            p0 += tl.N
+            tl.add_to_shared(b, shared)
+            if t == rank:
+                mine = _to_rows(g, b, tl.og.K2t, lay.rows(t))
+        ex = S.DistExchange(lay, None, "cpu")
+        ex.my_rows()[:lay.rows(rank)] = torch.from_numpy(mine)
+
+        def halo_add(recv):
+            ex.my_rows()[:3] += recv
+
+        ex.exchange(halo_add=halo_add)
+        full = ex.buf.view(-1)[torch.from_numpy(lay.row_offsets())[:, None] + torch.arange(n_cols)[None, :]].numpy()
+        err = np.abs(full - _patch_rows(g, shared)).max() / np.abs(shared).max()
+        q.put((rank, float(err)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case_name,world", [("rl_slab", 2), ("rlz_hrbl", 2), ("rl_slab", 3)])
+def test_halo_and_gather_reproduce_shared_sum(case_name, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert sorted(res) == list(range(world))
+    assert max(res.values()) < 1e-14

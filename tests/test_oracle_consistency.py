@@ -1,0 +1,135 @@
+"""CPU-only checks of the oracle itself: the loop-based C port against the dense numpy definition, and the
+mathematical properties the external (Springsteel) part must satisfy since no reference fixture pins it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.filterwarnings("ignore:divide by zero")
+
+from oracle import oracle_np as O
+from tests import cases
+
+
+@pytest.mark.parametrize("maker,kw,tiles,steps", [
+    (cases.r_bcs, dict(bcl="R1T0", bcr="R2T10"), None, 5),
+    (cases.rz_advection, {}, [(0, 4), (4, 6)], 4),
+    (cases.rz_semiimplicit, {}, [(0, 3), (3, 5)], 5),
+    (cases.rl_advection, {}, None, 4),
+    (cases.rl_advection, dict(ring_L=16), [(0, 3), (3, 5)], 4),
+    (cases.rl_slab, dict(twoway=True), [(0, 3), (3, 5)], 4),
+    (cases.rlz_hrbl, {}, [(0, 2), (2, 3)], 3),
+    (cases.rlz_hrbl, dict(ring_L=16), None, 3),
+    (cases.rlz_advection, {}, None, 3),
+])
+def test_c_port_equals_numpy_definition(maker, kw, tiles, steps):
+    case = maker(**kw)
+    a = cases.OracleModel(case, tiles=tiles)
+    b = cases.OracleModel(case, tiles=tiles, numpy_twin=True)
+    assert cases.rel_err(a.A, b.A) < 1e-12
+    for _ in range(steps):
+        a.step()
+        b.step()
+    assert cases.rel_err_per_var(a.physical(), b.physical()) < 5e-10
+
+
+def test_tiles_equal_single_patch():
+    case = cases.rl_slab(num_cells=9)
+    a = cases.OracleModel(case)
+    b = cases.OracleModel(case, tiles=[(0, 3), (3, 3), (6, 3)])
+    for _ in range(3):
+        a.step()
+        b.step()
+    assert cases.rel_err_per_var(b.physical(), a.physical()) < 1e-11
+
+
+@pytest.mark.parametrize("bcl,bcr", [("R1T0", "R0"), ("R1T1", "R1T0"), ("R1T2", "R1T1"), ("R2T10", "R2T20"), ("R3", "R3")])
+def test_radial_boundary_conditions_are_satisfied(bcl, bcr):
+    """The spline reconstructed from A coefficients obeys the stated condition at both ends to rounding."""
+    s = O.Spline1D(0.0, 7.0, 14, 2.0, bcl, bcr)
+    rng = np.random.default_rng(3)
+    a = s.SA(s.SB(rng.standard_normal(len(s.mish))))
+    ends = np.array([s.xmin, s.xmax])
+    val, d1, d2 = (s.basis(ends, d) @ a for d in range(3))
+    scale = np.abs(a).max()
+    for side, bc in ((0, bcl), (1, bcr)):
+        if bc in ("R1T0", "R2T10", "R2T20", "R3"):
+            assert abs(val[side]) < 1e-12 * scale
+        if bc in ("R1T1", "R2T10", "R3"):
+            assert abs(d1[side]) < 1e-12 * scale / s.DX
+        if bc in ("R1T2", "R2T20", "R3"):
+            assert abs(d2[side]) < 1e-12 * scale / s.DX ** 2
+
+
+def test_spline_roundtrip_and_rescaling_invariance():
+    """SA(SB(u)) reproduces an in-space function; physical answers are invariant under x -> lambda x."""
+    s1 = O.Spline1D(0.0, 10.0, 20, 2.0)
+    s2 = O.Spline1D(0.0, 1000.0, 20, 2.0)
+    f = lambda t: np.exp(-((t - 0.5) / 0.2) ** 2)
+    a1 = s1.SA(s1.SB(f(s1.mish / 10.0)))
+    a2 = s2.SA(s2.SB(f(s2.mish / 1000.0)))
+    assert np.max(np.abs(a1 - a2)) < 1e-12
+    d1 = s1.basis(s1.mish, 1) @ a1
+    d2 = s2.basis(s2.mish, 1) @ a2
+    assert np.max(np.abs(d1 - 100.0 * d2)) < 1e-10
+    # the filter penalises the third derivative only, so a quadratic is reproduced exactly
+    p = lambda x: 1.0 + 0.3 * x - 0.02 * x ** 2
+    a = s1.SA(s1.SB(p(s1.mish)))
+    assert np.max(np.abs(s1.basis(s1.mish, 0) @ a - p(s1.mish))) < 1e-11
+
+
+def test_fourier_ring_operators():
+    rg = O.Ring(20, 4, 0.37)
+    lam = rg.lam
+    u = 0.3 + np.cos(2 * lam) - 0.5 * np.sin(3 * lam) + 0.25 * np.cos(4 * lam + 0.2)
+    c = rg.FB @ u
+    assert np.max(np.abs(rg.FI[0] @ c - u)) < 1e-13
+    du = -2 * np.sin(2 * lam) - 1.5 * np.cos(3 * lam) - np.sin(4 * lam + 0.2)
+    ddu = -4 * np.cos(2 * lam) + 4.5 * np.sin(3 * lam) - 4 * np.cos(4 * lam + 0.2)
+    assert np.max(np.abs(rg.FI[1] @ c - du)) < 1e-12
+    assert np.max(np.abs(rg.FI[2] @ c - ddu)) < 1e-12
+    # all rings share the lambda = 0 phase reference: the same field gives the same coefficients on a shifted ring
+    rg2 = O.Ring(28, 4, 1.1)
+    u2 = 0.3 + np.cos(2 * rg2.lam) - 0.5 * np.sin(3 * rg2.lam) + 0.25 * np.cos(4 * rg2.lam + 0.2)
+    assert np.max(np.abs(rg2.FB @ u2 - c)) < 1e-13
+
+
+def test_chebyshev_operators():
+    ch = O.Cheb(0.0, 5.0, 24, 24)
+    z = ch.z
+    assert z[0] == 0.0 and abs(z[-1] - 5.0) < 1e-14            # index 0 is the bottom
+    f, fz, fzz = np.exp(0.3 * z) * np.sin(z), None, None
+    fz = np.exp(0.3 * z) * (0.3 * np.sin(z) + np.cos(z))
+    fzz = np.exp(0.3 * z) * ((0.09 - 1) * np.sin(z) + 0.6 * np.cos(z))
+    b = ch.CBm @ f
+    assert np.max(np.abs(ch.M[0] @ b - f)) < 1e-12             # CI(CA(CB u)) = u when nothing is truncated
+    assert np.max(np.abs(ch.M[1] @ b - fz)) < 1e-9
+    assert np.max(np.abs(ch.M[2] @ b - fzz)) < 1e-7
+    integ = ch.Mint @ b                                         # integral from the bottom
+    exact = (np.exp(0.3 * z) * (0.3 * np.sin(z) - np.cos(z)) + 1.0) / (0.09 + 1.0)
+    assert abs(integ[0]) < 1e-13 and np.max(np.abs(integ - exact)) < 1e-11
+    # collocation matrices agree with the coefficient recurrences (dct_1st/2nd_derivative vs CIx/CIxx)
+    a = np.linalg.solve(ch.dct_matrix(), f)
+    assert np.max(np.abs(ch.dct_1st_derivative() @ a - ch.M[1] @ b)) < 1e-9
+    assert np.max(np.abs(ch.dct_2nd_derivative() @ a - ch.M[2] @ b)) < 1e-7
+    assert O.default_bzdim(64) == 43 and O.default_bzdim(128) == 86
+
+
+@pytest.mark.parametrize("bcb,bct", [("R1T0", "R0"), ("R1T1", "R1T0"), ("R0", "R1T1")])
+def test_vertical_boundary_conditions_are_satisfied(bcb, bct):
+    ch = O.Cheb(0.0, 3.0, 16, 11, bcb, bct)
+    b = np.random.default_rng(5).standard_normal(11)
+    val, dz = ch.M[0] @ b, ch.M[1] @ b
+    for idx, bc in ((0, bcb), (-1, bct)):
+        if bc == "R1T0":
+            assert abs(val[idx]) < 1e-12
+        if bc == "R1T1":
+            assert abs(dz[idx]) < 1e-11
+
+
+def test_helmholtz_solution_satisfies_dirichlet_rows():
+    """rows 1-2 of H impose w = 0 at bottom and top (src/semiimplicit.jl:777-779)."""
+    ch = O.Cheb(0.0, 1.0e4, 16, 16)
+    H = O.helmholtz_matrix(ch, 1.2e5, 2.5)
+    g = np.zeros(16)
+    g[2:] = np.random.default_rng(7).standard_normal(14)
+    w = ch.T @ np.linalg.solve(H, g)
+    assert abs(w[0]) < 1e-9 * np.abs(w).max() and abs(w[-1]) < 1e-9 * np.abs(w).max()
