@@ -452,6 +452,55 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         if (!dalloc(h, &h->d_Btile_own, (size_t)h->nbt * C)) FAIL();
         h->d_Btile = h->d_Btile_own;
     }
+    {   // derivative slots each equation set reads (everything else is skipped by sx_advance's inverse transform)
+        const int u = 1 << h->slot[0], r = 1 << h->slot[1], rr = 1 << h->slot[2];
+        const int l = h->has_l ? 1 << h->slot[3] : 0, ll = h->has_l ? 1 << h->slot[4] : 0;
+        const int z = h->has_z ? 1 << h->slot[5] : 0, zz = h->has_z ? 1 << h->slot[6] : 0;
+        std::vector<int> full(h->V, (1 << h->D) - 1), eq(h->V, u);
+        switch (h->eq) {
+            case SX_EQ_LINEAR_ADVECTION_1D: eq[0] = u | r | rr; break;
+            case SX_EQ_LINEAR_ADVECTION_RZ: eq[0] = u | r | rr | z | zz; break;
+            case SX_EQ_LINEAR_ADVECTION_RL: case SX_EQ_LINEAR_ADVECTION_RLZ: eq[0] = u | r | rr | l | ll; break;
+            case SX_EQ_ONEWAY_SW_SLAB: case SX_EQ_TWOWAY_SW_SLAB: case SX_EQ_ONEWAY_SW_HRBL:
+                eq[0] = eq[1] = eq[2] = u | r | l;
+                eq[3] = eq[4] = u | r | rr | l | ll | (h->eq == SX_EQ_ONEWAY_SW_HRBL ? z : 0);
+                eq[5] = 0;        // w is diagnostic: written by the equation set before it is read
+                break;
+            case SX_EQ_LINEAR_ACOUSTIC_RZ:
+                eq[0] = eq[2] = eq[3] = eq[4] = u | r | rr | z | zz;
+                eq[1] = u | r | z;
+                break;
+            default: break;
+        }
+        for (int v = 0; v < h->V; v++) {
+            h->mask_full_bits += __builtin_popcount(full[v]);
+            h->mask_eq_bits += __builtin_popcount(eq[v]);
+        }
+        if (!upload(h, &h->d_mask_full, full) || !upload(h, &h->d_mask_eq, eq)) FAIL();
+        if (h->has_z) {   // vertical-transform job lists: only the (variable, operator) pairs some requested slot needs
+            const int horiz = u | r | rr | l | ll;
+            std::vector<ColJob> jf, je, jz;
+            for (int v = 0; v < h->V; v++) {
+                for (int sz = 0; sz < 3; sz++) {
+                    ColJob j;
+                    j.in_off = (int64_t)v * h->Zb * h->K2;
+                    j.out_off = ((int64_t)v * 3 + sz) * h->nz * h->K2;
+                    j.mat_off = ((int64_t)v * 3 + sz) * h->nz * h->Zb;
+                    jf.push_back(j);
+                    const int need = sz == 0 ? horiz : sz == 1 ? z : zz;
+                    if (eq[v] & need) je.push_back(j);
+                }
+                ColJob f;
+                f.in_off = (int64_t)v * h->nz * h->K2;
+                f.out_off = (int64_t)v * h->Zb * h->K2;
+                f.mat_off = 0;
+                jz.push_back(f);
+            }
+            h->njobs_zinv_full = (int)jf.size();
+            h->njobs_zinv_eq = (int)je.size();
+            if (!upload(h, &h->d_jobs_zinv_full, jf) || !upload(h, &h->d_jobs_zinv_eq, je) || !upload(h, &h->d_jobs_zf, jz)) FAIL();
+        }
+    }
     if (sx_bind_patch_b(h, nullptr, nullptr)) FAIL();
     *out = h;
     return status();
@@ -616,8 +665,8 @@ int sx_spline_transform(sx_handle *h) {
 int sx_tile_transform(sx_handle *h) {
     clear_error();
     if (!h) { set_error("null handle"); return 1; }
-    launch_zinv(h);
-    launch_rl_inverse(h);
+    launch_zinv(h, true);
+    launch_rl_inverse(h, true);
     return status();
 }
 
@@ -633,8 +682,8 @@ int sx_advance(sx_handle *h, int32_t t) {
     clear_error();
     if (!h) { set_error("null handle"); return 1; }
     if (t < 1) { set_error("t is 1-based"); return 1; }
-    launch_zinv(h);
-    launch_rl_inverse(h);
+    launch_zinv(h, false);
+    launch_rl_inverse(h, false);
     launch_physics(h, t);
     launch_fl_forward(h);
     launch_sb(h);
@@ -738,13 +787,15 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     // Algorithmic bytes per launch (fp64), counting each array once (DESIGN.md "Kernels and rooflines").
     const double w = 8.0, N = (double)h->N, V = h->V, D = h->D;
     const double S_tile = (double)h->nbt * h->C, S_patch = (double)h->b_rDim * h->C;
-    const double az = h->has_z ? (double)h->nbt * h->V * 3 * h->nz * h->K2 : S_tile;
+    const double az = h->has_z ? (double)h->nbt * h->last_zinv_jobs * h->nz * h->K2 : S_tile;
     const double fl = (double)h->nrings * h->V * h->nz * h->K2, bz = (double)h->nbt * h->V * h->nz * h->K2;
     std::string k(name);
     double b = 0;
-    if (k == "k_rl_inverse") b = w * (N * V * D + az);              // write physical, read the z-inverted coefficients
+    const double planes = h->last_mask_full ? h->mask_full_bits : h->mask_eq_bits;   // (variable, slot) planes produced
+    (void)D;
+    if (k == "k_rl_inverse") b = w * (N * planes + az);             // write the requested physical planes, read Az
     else if (k == "k_zinv") b = w * (S_tile + az);
-    else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") b = w * N * V * (D + 4.0);  // read physical, E_nm1, E_nm2; write E_n, var_np1
+    else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") b = w * N * (h->mask_eq_bits + 4.0 * V);  // read slots, E_nm1, E_nm2; write E_n, var_np1
     else if (k == "k_fl_forward") b = w * (N * V + fl);
     else if (k == "k_sb") b = w * (fl + bz);
     else if (k == "k_zf") b = w * (bz + S_tile);

@@ -44,6 +44,10 @@ bool build_helmholtz(const ChebOps &w, double pxi_bar, double tau, std::vector<d
 void ring_table(int has_l, int uniform_L, int ri /*1-based patch ring*/, int &L, int &kmax, double &off);
 
 // ---- device-side tables handed to the kernels -----------------------------------------------------------------------
+struct ColJob {
+    int64_t in_off, out_off, mat_off;
+};
+
 struct Timer {
     const char *name;
     double ms = 0.0;
@@ -93,6 +97,11 @@ struct sx_handle {
     double *d_gl = nullptr, *d_gr = nullptr, *d_Lband = nullptr, *d_Larrow = nullptr;
     double *d_r = nullptr, *d_cosl = nullptr, *d_sinl = nullptr, *d_z = nullptr;
     int *d_flag = nullptr;
+    int *d_mask_full = nullptr, *d_mask_eq = nullptr;   // per-variable bit masks of derivative slots to produce
+    int mask_eq_bits = 0, mask_full_bits = 0;            // total number of (variable, slot) planes in each mask
+    bool last_mask_full = true;
+    sx::ColJob *d_jobs_zinv_full = nullptr, *d_jobs_zinv_eq = nullptr, *d_jobs_zf = nullptr;
+    int njobs_zinv_full = 0, njobs_zinv_eq = 0, last_zinv_jobs = 0;
     int ncls = 0;
     size_t dev_bytes = 0;
     std::vector<void *> allocs;
@@ -105,8 +114,11 @@ struct sx_handle {
 
 namespace sx {
 // kernel launchers (sx_kernels.hip); each returns hipError_t from the launch
-void launch_zinv(sx_handle *h);
-void launch_rl_inverse(sx_handle *h);
+void launch_zinv(sx_handle *h, bool full);
+void launch_rl_inverse(sx_handle *h, bool full);
+bool fft_path_ok(const sx_handle *h);
+void launch_rl_inverse_fft(sx_handle *h, const int *d_mask);
+void launch_fl_forward_fft(sx_handle *h);
 void launch_physics(sx_handle *h, int t);
 void launch_copy_slot0(sx_handle *h);
 void launch_fl_forward(sx_handle *h);

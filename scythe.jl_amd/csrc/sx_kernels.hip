@@ -23,20 +23,46 @@ namespace sx {
 
 constexpr int ZC = 16;   // z-levels per workgroup in the ring kernels: 16 * 8 B = one 128-B line per (ring point)
 
-// ------------------------------------------------------------------------------------------------ vertical inverse
-// Az[j][v][sz][z][blk] = sum_zm Mz[v][sz][z][zm] * A[(cell0 + j)][v][zm][blk]
-__global__ void k_zinv(const double *__restrict__ A, double *__restrict__ Az, const double *__restrict__ Mz,
-                       int V, int nz, int Zb, int K2, int64_t C, int cell0) {
-    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = blockIdx.y;              // (v, sz, z)
-    const int j = blockIdx.z;
-    const int z = q % nz, sz = (q / nz) % 3, v = q / (3 * nz);
-    if (blk >= K2) return;
-    const double *a = A + (int64_t)(cell0 + j) * C + (int64_t)v * Zb * K2 + blk;
-    const double *m = Mz + (((int64_t)v * 3 + sz) * nz + z) * Zb;
-    double s = 0.0;
-    for (int zm = 0; zm < Zb; zm++) s += m[zm] * a[(int64_t)zm * K2];
-    Az[((((int64_t)j * V + v) * 3 + sz) * nz + z) * K2 + blk] = s;
+// ------------------------------------------------------------------------------------------------ vertical transforms
+// Dense Chebyshev collocation products on spectral-sized data, one "job" per (variable, operator):
+//   out[row][job.out_off + o*K2 + blk] = sum_i M[job.mat_off + o*n_in + i] * in[row0 + row][job.in_off + i*K2 + blk]
+// inverse: in = A rows, M = Mz[v][sz] (b -> value / d/dz / d2/dz2 incl. BC projection), out = Az
+// forward: in = Bz rows, M = CB (values -> truncated b), out = B
+// Workgroup = 64 wavenumber blocks x 4 output groups; the input tile sits in LDS, the operator entries are
+// wave-uniform (scalar loads), every thread accumulates 4 outputs per pass over the input.
+__global__ void __launch_bounds__(256)
+k_colmat(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ mats,
+         const ColJob *__restrict__ jobs, int n_in, int n_out, int K2, int64_t in_row, int64_t out_row, int row0) {
+    extern __shared__ double As[];
+    const int lane = threadIdx.x, g = threadIdx.y;
+    const int blk = blockIdx.x * 64 + lane;
+    const ColJob job = jobs[blockIdx.y];
+    const double *src = in + (int64_t)(row0 + blockIdx.z) * in_row + job.in_off;
+    double *dst = out + (int64_t)blockIdx.z * out_row + job.out_off;
+    const double *M = mats + job.mat_off;
+    const bool ok = blk < K2;
+    for (int i = g; i < n_in; i += 4) As[i * 64 + lane] = ok ? src[(int64_t)i * K2 + blk] : 0.0;
+    __syncthreads();
+    for (int o0 = g * 4; o0 < n_out; o0 += 16) {
+        const double *m0 = M + (int64_t)o0 * n_in;
+        const double *m1 = M + (int64_t)min(o0 + 1, n_out - 1) * n_in;
+        const double *m2 = M + (int64_t)min(o0 + 2, n_out - 1) * n_in;
+        const double *m3 = M + (int64_t)min(o0 + 3, n_out - 1) * n_in;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int i = 0; i < n_in; i++) {
+            const double x = As[i * 64 + lane];
+            a0 += m0[i] * x;
+            a1 += m1[i] * x;
+            a2 += m2[i] * x;
+            a3 += m3[i] * x;
+        }
+        if (ok) {
+            dst[(int64_t)o0 * K2 + blk] = a0;
+            if (o0 + 1 < n_out) dst[(int64_t)(o0 + 1) * K2 + blk] = a1;
+            if (o0 + 2 < n_out) dst[(int64_t)(o0 + 2) * K2 + blk] = a2;
+            if (o0 + 3 < n_out) dst[(int64_t)(o0 + 3) * K2 + blk] = a3;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ radial + azimuthal inverse
@@ -47,9 +73,11 @@ k_rl_inverse(const double *__restrict__ Az, double *__restrict__ phys, const dou
              const int *__restrict__ Lr, const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart,
              const int64_t *__restrict__ twoff, const double2 *__restrict__ tw, const int64_t *__restrict__ phoff,
              const double2 *__restrict__ ph, int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
-             int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz, int has_l, int cstride) {
+             int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz, int has_l, int cstride,
+             const int *__restrict__ slotmask) {
     extern __shared__ double sm[];
     const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * ZC;
+    const int mask = slotmask[v];
     const int zc = min(ZC, nz - z0);
     const int L = Lr[ring], km = has_l ? kmaxr[ring] : 0;
     const int j0 = ring / MUBAR;
@@ -64,6 +92,9 @@ k_rl_inverse(const double *__restrict__ Az, double *__restrict__ phys, const dou
         const int sz = q < 3 ? 0 : q - 2, d = q < 3 ? q : 0;
         if (sz >= nsz) break;
         const int slot0 = (q == 0) ? s_u : (q == 1) ? s_r : (q == 2) ? s_rr : (q == 3) ? s_z : s_zz;
+        const bool need0 = (mask >> slot0) & 1;
+        const bool needl = (q == 0) && has_l && ((mask >> s_l) & 1), needll = (q == 0) && has_l && ((mask >> s_ll) & 1);
+        if (!need0 && !needl && !needll) continue;
         const double *p = phi + ((int64_t)d * nrings + ring) * 4;
         const double f0 = p[0], f1 = p[1], f2 = p[2], f3 = p[3];
         __syncthreads();
@@ -87,7 +118,7 @@ k_rl_inverse(const double *__restrict__ Az, double *__restrict__ phys, const dou
             cI[zz * cstride + k] = ci;
         }
         __syncthreads();
-        const bool lamder = (q == 0) && has_l;
+        const bool lamder = needl || needll;
         for (int o = tid; o < L * zc; o += blockDim.x) {
             const int zz = o % zc, l = o / zc;
             const double *r = cR + zz * cstride, *im = cI + zz * cstride;
@@ -105,11 +136,9 @@ k_rl_inverse(const double *__restrict__ Az, double *__restrict__ phys, const dou
                 }
             }
             const int64_t pt = (p0 + l) * nz + z0 + zz;
-            phys[((int64_t)slot0 * V + v) * N + pt] = a0;
-            if (lamder) {
-                phys[((int64_t)s_l * V + v) * N + pt] = a1;
-                phys[((int64_t)s_ll * V + v) * N + pt] = a2;
-            }
+            if (need0) phys[((int64_t)slot0 * V + v) * N + pt] = a0;
+            if (needl) phys[((int64_t)s_l * V + v) * N + pt] = a1;
+            if (needll) phys[((int64_t)s_ll * V + v) * N + pt] = a2;
         }
     }
 }
@@ -174,22 +203,6 @@ __global__ void k_sb(const double *__restrict__ Fl, double *__restrict__ Bz, con
         }
     }
     Bz[(int64_t)j * plane + e] = s;
-}
-
-// ------------------------------------------------------------------------------------------------ vertical forward
-// B[j][v][zm][blk] = sum_z CB[zm][z] Bz[j][v][z][blk]
-__global__ void k_zf(const double *__restrict__ Bz, double *__restrict__ B, const double *__restrict__ CB, int V, int nz,
-                     int Zb, int K2) {
-    const int blk = blockIdx.x * blockDim.x + threadIdx.x;
-    const int q = blockIdx.y;       // (v, zm)
-    const int j = blockIdx.z;
-    const int zm = q % Zb, v = q / Zb;
-    if (blk >= K2) return;
-    const double *x = Bz + (((int64_t)j * V + v) * nz) * K2 + blk;
-    const double *c = CB + (int64_t)zm * nz;
-    double s = 0.0;
-    for (int z = 0; z < nz; z++) s += c[z] * x[(int64_t)z * K2];
-    B[(int64_t)j * V * Zb * K2 + ((int64_t)v * Zb + zm) * K2 + blk] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ B -> A banded SPD solve
@@ -552,18 +565,26 @@ __global__ void __launch_bounds__(256) k_semiimplicit(SemiArgs a, int cpb) {
 // ------------------------------------------------------------------------------------------------ launchers
 static inline dim3 grid1(int64_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
-void launch_zinv(sx_handle *h) {
+void launch_zinv(sx_handle *h, bool full) {
     if (!h->has_z) return;
     const int id = timer_id(h, "k_zinv");
     timer_begin(h, id);
-    dim3 g((h->K2 + 255) / 256, h->V * 3 * h->nz, h->nbt);
-    hipLaunchKernelGGL(k_zinv, g, dim3(256), 0, h->stream, h->d_A, h->d_Az, h->d_Mz, h->V, h->nz, h->Zb, h->K2, h->C,
-                       h->cell0);
-    HIPCHK(hipGetLastError());
+    const int njobs = full ? h->njobs_zinv_full : h->njobs_zinv_eq;
+    h->last_zinv_jobs = njobs;
+    if (njobs > 0) {
+        dim3 g((h->K2 + 63) / 64, njobs, h->nbt);
+        hipLaunchKernelGGL(k_colmat, g, dim3(64, 4), sizeof(double) * 64 * h->Zb, h->stream, h->d_A, h->d_Az, h->d_Mz,
+                           full ? h->d_jobs_zinv_full : h->d_jobs_zinv_eq, h->Zb, h->nz, h->K2, h->C,
+                           (int64_t)h->V * 3 * h->nz * h->K2, h->cell0);
+        HIPCHK(hipGetLastError());
+    }
     timer_end(h);
 }
 
-void launch_rl_inverse(sx_handle *h) {
+void launch_rl_inverse(sx_handle *h, bool full) {
+    const int *mask = full ? h->d_mask_full : h->d_mask_eq;
+    h->last_mask_full = full;
+    if (fft_path_ok(h)) { launch_rl_inverse_fft(h, mask); return; }
     const int id = timer_id(h, "k_rl_inverse");
     timer_begin(h, id);
     const int cstride = (h->kmax_max + 1) | 1;
@@ -573,7 +594,7 @@ void launch_rl_inverse(sx_handle *h) {
     dim3 g((h->nz + ZC - 1) / ZC, h->V, h->nrings);
     hipLaunchKernelGGL(k_rl_inverse, g, dim3(256), lds, h->stream, az, h->d_phys, h->d_phi, h->d_L, h->d_kmax, h->d_pstart,
                        h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2, h->nrings, h->N, azrow,
-                       h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6], h->has_l, cstride);
+                       h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6], h->has_l, cstride, mask);
     HIPCHK(hipGetLastError());
     timer_end(h);
 }
@@ -638,6 +659,7 @@ void launch_physics(sx_handle *h, int t) {
 }
 
 void launch_fl_forward(sx_handle *h) {
+    if (fft_path_ok(h)) { launch_fl_forward_fft(h); return; }
     const int id = timer_id(h, "k_fl_forward");
     timer_begin(h, id);
     const int xstride = h->L_max | 1;
@@ -664,8 +686,9 @@ void launch_zf(sx_handle *h) {
     if (!h->has_z) return;
     const int id = timer_id(h, "k_zf");
     timer_begin(h, id);
-    dim3 g((h->K2 + 255) / 256, h->V * h->Zb, h->nbt);
-    hipLaunchKernelGGL(k_zf, g, dim3(256), 0, h->stream, h->d_Bz, h->d_Btile, h->d_CB, h->V, h->nz, h->Zb, h->K2);
+    dim3 g((h->K2 + 63) / 64, h->V, h->nbt);
+    hipLaunchKernelGGL(k_colmat, g, dim3(64, 4), sizeof(double) * 64 * h->nz, h->stream, h->d_Bz, h->d_Btile, h->d_CB,
+                       h->d_jobs_zf, h->nz, h->Zb, h->K2, (int64_t)h->V * h->nz * h->K2, h->C, 0);
     HIPCHK(hipGetLastError());
     timer_end(h);
 }

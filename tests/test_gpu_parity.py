@@ -53,6 +53,16 @@ def test_rlz_hrbl(ring_L):
     assert _run(cases.rlz_hrbl(ring_L=ring_L), 4) < TOL
 
 
+@pytest.mark.parametrize("ring_L,zDim,cells", [(256, 20, 4), (64, 16, 5), (128, 9, 4)])
+def test_rlz_hrbl_fft_rings(ring_L, zDim, cells):
+    """Power-of-two uniform rings take the Stockham FFT kernels (incl. partial z-chunks and odd log2 L)."""
+    assert _run(cases.rlz_hrbl(num_cells=cells, zDim=zDim, ring_L=ring_L), 3) < TOL
+
+
+def test_rl_slab_fft_rings():
+    assert _run(cases.rl_slab(ring_L=64), 4) < TOL
+
+
 def test_rlz_advection():
     assert _run(cases.rlz_advection(), 6) < TOL
 
