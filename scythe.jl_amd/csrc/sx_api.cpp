@@ -128,6 +128,8 @@ static int default_bzdim(int zDim) {
 
 // reference layout index of (zm, blk, node) inside one variable's spectral column
 static inline int64_t ref_index(int zm, int blk, int node, int K2, int nb) { return ((int64_t)zm * K2 + blk) * nb + node; }
+// device block index of reference block b (0: k = 0, 2k-1: Re k, 2k: Im k)
+static inline int dev_blk(int b) { return b == 0 ? 0 : b + 1; }
 
 }  // namespace sx
 
@@ -306,7 +308,8 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         ring_table(h->has_l, h->uniform_L, r + 1, L, km, off);
         h->kDim = std::max(h->kDim, km);
     }
-    h->K2 = 1 + 2 * h->kDim;
+    h->K2ref = 1 + 2 * h->kDim;
+    h->K2 = h->has_l ? 2 * (h->kDim + 1) : 1;
     h->hL.resize(h->nrings); h->hkmax.resize(h->nrings); h->hoff.resize(h->nrings); h->hpstart.resize(h->nrings);
     std::vector<int64_t> twoff(h->nrings), phoff(h->nrings);
     std::vector<double2> tw, ph;
@@ -337,7 +340,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->Nh = pcount;
     h->N = pcount * h->nz;
     h->C = (int64_t)h->V * h->Zb * h->K2;
-    h->S_patch = (int64_t)h->Zb * h->K2 * h->b_rDim;
+    h->S_patch = (int64_t)h->Zb * h->K2ref * h->b_rDim;
     h->S_tile = (int64_t)h->Zb * h->K2t * h->nbt;
 
     // ---- radial tables
@@ -523,7 +526,7 @@ int sx_get_dims(const sx_handle *h, sx_dims *o) {
     o->n_points = h->N; o->n_hpoints = h->Nh; o->n_vars = h->V; o->n_derivs = h->D; o->n_coord = h->ncoord;
     o->rDim = h->rDim; o->b_rDim = h->b_rDim; o->tile_rDim = h->nrings; o->tile_b_rDim = h->nbt;
     o->zDim = h->has_z ? h->nz : 0; o->b_zDim = h->has_z ? h->Zb : 0;
-    o->kDim = h->kDim; o->n_blocks = h->K2; o->tile_kDim = h->kDim_t; o->tile_n_blocks = h->K2t;
+    o->kDim = h->kDim; o->n_blocks = h->K2ref; o->tile_kDim = h->kDim_t; o->tile_n_blocks = h->K2t;
     o->s_patch = h->S_patch; o->s_tile = h->S_tile; o->n_cols = h->C;
     return 0;
 }
@@ -602,18 +605,18 @@ int sx_get_tile_spectral(sx_handle *h, double *out) {
             for (int blk = 0; blk < h->K2t; blk++)
                 for (int j = 0; j < h->nbt; j++)
                     out[(int64_t)v * h->S_tile + ref_index(zm, blk, j, h->K2t, h->nbt)] =
-                        tmp[(size_t)j * h->C + ((size_t)v * h->Zb + zm) * h->K2 + blk];
+                        tmp[(size_t)j * h->C + ((size_t)v * h->Zb + zm) * h->K2 + dev_blk(blk)];
     return status();
 }
 
 static int patch_to_device(sx_handle *h, const double *src, double *dst) {
-    std::vector<double> tmp((size_t)h->b_rDim * h->C);
+    std::vector<double> tmp((size_t)h->b_rDim * h->C, 0.0);
     for (int v = 0; v < h->V; v++)
         for (int zm = 0; zm < h->Zb; zm++)
-            for (int blk = 0; blk < h->K2; blk++)
+            for (int blk = 0; blk < h->K2ref; blk++)
                 for (int m = 0; m < h->b_rDim; m++)
-                    tmp[(size_t)m * h->C + ((size_t)v * h->Zb + zm) * h->K2 + blk] =
-                        src[(int64_t)v * h->S_patch + ref_index(zm, blk, m, h->K2, h->b_rDim)];
+                    tmp[(size_t)m * h->C + ((size_t)v * h->Zb + zm) * h->K2 + dev_blk(blk)] =
+                        src[(int64_t)v * h->S_patch + ref_index(zm, blk, m, h->K2ref, h->b_rDim)];
     HIPOK(hipMemcpyAsync(dst, tmp.data(), sizeof(double) * tmp.size(), hipMemcpyHostToDevice, h->stream));
     HIPOK(hipStreamSynchronize(h->stream));
     return status();
@@ -639,10 +642,10 @@ int sx_get_patch_spectral_a(sx_handle *h, double *out) {
     HIPOK(hipStreamSynchronize(h->stream));
     for (int v = 0; v < h->V; v++)
         for (int zm = 0; zm < h->Zb; zm++)
-            for (int blk = 0; blk < h->K2; blk++)
+            for (int blk = 0; blk < h->K2ref; blk++)
                 for (int m = 0; m < h->b_rDim; m++)
-                    out[(int64_t)v * h->S_patch + ref_index(zm, blk, m, h->K2, h->b_rDim)] =
-                        tmp[(size_t)m * h->C + ((size_t)v * h->Zb + zm) * h->K2 + blk];
+                    out[(int64_t)v * h->S_patch + ref_index(zm, blk, m, h->K2ref, h->b_rDim)] =
+                        tmp[(size_t)m * h->C + ((size_t)v * h->Zb + zm) * h->K2 + dev_blk(blk)];
     return status();
 }
 

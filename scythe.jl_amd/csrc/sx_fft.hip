@@ -2,10 +2,15 @@
 // "perf shape").  Rings of any other length use the direct truncated DFT in sx_kernels.hip.
 //
 // One workgroup = (z-chunk of 16 levels, variable, ring).  Two vertical levels are packed into one complex
-// transform (level 2p -> real part, 2p+1 -> imaginary part), so a chunk needs 8 complex FFTs per derivative slot,
-// all resident in LDS at once; results leave LDS as full 128-byte lines of the reference physical layout
-// (z innermost).  Radix-4 autosort passes (+ one radix-2 pass when log2 L is odd), twiddles from an LDS table.
+// transform (level 2p -> real part, 2p+1 -> imaginary part): 8 complex transforms per derivative slot and chunk.
+// A transform of length L is owned by L/4 lanes of ONE wave (L <= 256), so every pass is wave-local: in-place radix-4
+// autosort passes through a 16 B x L LDS region (+ one radix-2 pass when log2 L is odd), twiddles held in registers,
+// no workgroup barrier inside a transform.
+//   inverse: the last pass stores straight to the reference physical layout (z innermost): each lane writes the
+//            16-byte (z, z+1) pair of its ring points; the 8 waves of the workgroup complete every 128-byte line.
+//   forward: the workgroup first stages the [ring point][16 levels] tile through LDS with full 128-byte loads.
 #include "sx_internal.hpp"
+#include <cstdlib>
 
 namespace sx {
 
@@ -17,192 +22,257 @@ namespace sx {
 
 constexpr int FZC = 16;        // z levels per workgroup
 constexpr int FNP = FZC / 2;   // complex transforms per slot and workgroup
-constexpr int FTHREADS = 512;
-constexpr int SKEW = 2;        // complex elements of skew between transform buffers (LDS bank spreading)
+constexpr int SKEW = 2;        // complex elements of skew between transform regions (bank spreading when L < 256)
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ double2 cmuli(double2 a, int sign) { return sign > 0 ? make_double2(-a.y, a.x) : make_double2(a.y, -a.x); }
 
-// All FNP transforms of the workgroup advance together; transform f uses threads [f*T, (f+1)*T), T = L/4.
-// src/dst: base of the two buffer sets, transform f at offset f*(L+SKEW). Returns the set holding the result.
-template <int SIGN>
-__device__ double2 *stockham_pow2(double2 *src, double2 *dst, const double2 *tw, int L, int logL, int f, int t, bool active) {
-    const int T = L >> 2;
-    double2 *a = src + f * (L + SKEW), *b = dst + f * (L + SKEW);
+// orders LDS traffic between the lanes of one wave (DS instructions of a wave execute in issue order)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int LOGL>
+struct Twiddles {
+    static constexpr int L = 1 << LOGL, T = L / 4, NP4 = LOGL / 2;
+    double2 w1[NP4 > 1 ? NP4 - 1 : 1];     // w2 = w1^2, w3 = w1^3 are formed on the fly (registers are the scarce resource)
+    double2 r2a, r2b;
+    // SIGN = +1: e^{+i...} (inverse), -1: forward
+    template <int SIGN>
+    __device__ void init(const double2 *__restrict__ twg, int t) {
+        int Ns = 4;
+#pragma unroll
+        for (int p = 1; p < NP4; p++) {
+            const int s = (t & (Ns - 1)) * (L / (4 * Ns));
+            w1[p - 1] = twg[s];
+            if (SIGN < 0) w1[p - 1].y = -w1[p - 1].y;
+            Ns <<= 2;
+        }
+        if (LOGL & 1) {
+            r2a = twg[t]; r2b = twg[t + T];
+            if (SIGN < 0) { r2a.y = -r2a.y; r2b.y = -r2b.y; }
+        }
+    }
+};
+
+// In-place radix-4 passes on X (L complex, owned by T = L/4 lanes of one wave, lane index t).
+// All passes but the last are done here; `last` receives the outputs of the final pass:
+//   last(index, value) for the 4 (radix-4 ending) or 2 x 2 (radix-2 ending) outputs of this lane.
+struct NoSink {
+    __device__ void operator()(int, double2) const {}
+};
+
+// TO_LDS = true: the final pass is written back to X as well (natural order), `last` is not called.
+template <int LOGL, int SIGN, bool TO_LDS = false, class F = NoSink>
+__device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw, int t, bool active, F last = F()) {
+    constexpr int L = 1 << LOGL, T = L / 4, NP4 = LOGL / 2;
     int Ns = 1;
-    for (int p = 0; p < (logL >> 1); p++) {
+#pragma unroll
+    for (int p = 0; p < NP4; p++) {
+        double2 y0, y1, y2, y3;
+        int j0 = 0;
         if (active) {
             const int k = t & (Ns - 1);
-            double2 v0 = a[t], v1 = a[t + T], v2 = a[t + 2 * T], v3 = a[t + 3 * T];
-            if (Ns > 1) {
-                const int s = k * (L / (4 * Ns));
-                double2 w1 = tw[s], w2 = tw[2 * s], w3 = tw[3 * s];
-                if (SIGN < 0) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+            double2 v0 = X[t], v1 = X[t + T], v2 = X[t + 2 * T], v3 = X[t + 3 * T];
+            if (p > 0) {
+                const double2 w1 = tw.w1[p - 1], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
                 v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
             }
-            const double2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), d = csub(v1, v3);
-            const double2 t3 = SIGN > 0 ? make_double2(-d.y, d.x) : make_double2(d.y, -d.x);   // (+/- i) * d
-            const int j0 = ((t - k) << 2) + k;
-            b[j0] = cadd(t0, t2);
-            b[j0 + Ns] = cadd(t1, t3);
-            b[j0 + 2 * Ns] = csub(t0, t2);
-            b[j0 + 3 * Ns] = csub(t1, t3);
+            const double2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), t3 = cmuli(csub(v1, v3), SIGN);
+            y0 = cadd(t0, t2); y1 = cadd(t1, t3); y2 = csub(t0, t2); y3 = csub(t1, t3);
+            j0 = ((t - k) << 2) + k;
         }
-        __syncthreads();
-        double2 *tmp = a; a = b; b = tmp;
-        tmp = src; src = dst; dst = tmp;
+        if (!TO_LDS && p == NP4 - 1 && !(LOGL & 1)) {
+            if (active) { last(j0, y0); last(j0 + Ns, y1); last(j0 + 2 * Ns, y2); last(j0 + 3 * Ns, y3); }
+            return;
+        }
+        wave_sync();      // every lane has read its inputs before any lane overwrites them
+        if (active) { X[j0] = y0; X[j0 + Ns] = y1; X[j0 + 2 * Ns] = y2; X[j0 + 3 * Ns] = y3; }
+        wave_sync();
         Ns <<= 2;
     }
-    if (logL & 1) {       // final radix-2 pass, Ns = L/2
+    if (LOGL & 1) {       // final radix-2 pass, Ns = L/2: butterflies j = t and t + T
+        double2 a0, a1, b0, b1;
         if (active) {
-            for (int q = 0; q < 2; q++) {
-                const int j = t + q * T;
-                double2 w = tw[j];
-                if (SIGN < 0) w.y = -w.y;
-                const double2 v0 = a[j], v1 = cmul(a[j + 2 * T], w);
-                b[j] = cadd(v0, v1);
-                b[j + Ns] = csub(v0, v1);
-            }
+            a0 = X[t]; a1 = cmul(X[t + 2 * T], tw.r2a);
+            b0 = X[t + T]; b1 = cmul(X[t + 3 * T], tw.r2b);
         }
-        __syncthreads();
-        double2 *tmp = src; src = dst; dst = tmp;
+        if (TO_LDS) {
+            wave_sync();
+            if (active) { X[t] = cadd(a0, a1); X[t + Ns] = csub(a0, a1); X[t + T] = cadd(b0, b1); X[t + T + Ns] = csub(b0, b1); }
+            wave_sync();
+        } else if (active) {
+            last(t, cadd(a0, a1)); last(t + Ns, csub(a0, a1));
+            last(t + T, cadd(b0, b1)); last(t + T + Ns, csub(b0, b1));
+        }
     }
-    return src;
 }
 
 // ------------------------------------------------------------------------------------------------ inverse
-__global__ void __launch_bounds__(FTHREADS)
+template <int LOGL, int COPYOUT>
+__global__ void __launch_bounds__(512, 4)
 k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const double *__restrict__ phi,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,
-                 int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow, int L, int logL,
+                 int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
                  int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz) {
+    constexpr int L = 1 << LOGL, T = L / 4;
     extern __shared__ double2 smf[];
     const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * FZC;
     const int zc = min(FZC, nz - z0);
     const int km = kmaxr[ring];
-    const int T = L >> 2, tid = threadIdx.x;
-    const int f = tid / T, t = tid - f * T;
-    const bool active = f < FNP;
-    double2 *tw = smf;                              // [L]
-    double2 *bufA = smf + L, *bufB = bufA + FNP * (L + SKEW);
-    for (int j = tid; j < L; j += FTHREADS) tw[j] = twg[j];
+    const int f = threadIdx.x / T, t = threadIdx.x - f * T;       // transform (z pair) and lane within it
+    const int za = 2 * f, zb = 2 * f + 1;
+    const bool active = (f < FNP) && (za < zc);
+    const bool hasb = zb < zc;
+    double2 *X = smf + f * (L + SKEW);
+    Twiddles<LOGL> tw;
+    tw.template init<+1>(twg, t);
     const int j0 = ring / MUBAR;
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int mask = slotmask[v];
-    // output slot table: (slot index, sz, radial derivative d, lambda derivative ld)
-    const int slots[7] = {s_u, s_r, s_rr, s_l, s_ll, s_z, s_zz};
-    const int szs[7] = {0, 0, 0, 0, 0, 1, 2}, ds[7] = {0, 1, 2, 0, 0, 0, 0}, lds[7] = {0, 0, 0, 1, 2, 0, 0};
-    for (int q = 0; q < 7; q++) {
-        const int slot = slots[q];
-        if (slot < 0 || szs[q] >= nsz || !((mask >> slot) & 1)) continue;      // uniform across the workgroup
-        const int ld = lds[q];
-        __syncthreads();
+    const int k1 = t, k2 = t + T;                                  // this lane's two wavenumbers (k2 < L/2)
+    const bool in1 = k1 <= km, in2 = k2 <= km;
+    const double2 ph1 = in1 ? phr[k1] : make_double2(1.0, 0.0), ph2 = in2 ? phr[k2] : make_double2(1.0, 0.0);
+    const bool pair_ok = ((nz & 1) == 0);                          // (z, z+1) pairs are 16-byte aligned
+
+    // groups of output slots that share one radial combination: (sz, d) = (0,0): u, l, ll; (0,1): r; (0,2): rr;
+    // (1,0): z; (2,0): zz.  The four radial rows are re-read (L2) per group so that only one combination is live.
+    for (int grp = 0; grp < 5; grp++) {
+        const int sz = grp < 3 ? 0 : grp - 2, d = grp < 3 ? grp : 0;
+        if (sz >= nsz) break;
+        // candidate slots of this group, indexed by the lambda-derivative order ld
+        const int sl0 = grp == 0 ? s_u : grp == 1 ? s_r : grp == 2 ? s_rr : grp == 3 ? s_z : s_zz;
+        const int sl1 = grp == 0 ? s_l : -1, sl2 = grp == 0 ? s_ll : -1;
+        const bool n0 = sl0 >= 0 && ((mask >> sl0) & 1), n1 = sl1 >= 0 && ((mask >> sl1) & 1), n2 = sl2 >= 0 && ((mask >> sl2) & 1);
+        if (!n0 && !n1 && !n2) continue;
+        double2 a1 = make_double2(0.0, 0.0), b1 = a1, a2 = a1, b2 = a1;
         if (active) {
-            const double *pf = phi + ((int64_t)ds[q] * nrings + ring) * 4;
-            const double f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
-            const int za = 2 * f, zb = 2 * f + 1;
-            const bool hasa = za < zc, hasb = zb < zc;
-            const double *a0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + szs[q]) * nz + (z0 + (hasa ? za : 0))) * K2;
-            const double *b0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + szs[q]) * nz + (z0 + (hasb ? zb : 0))) * K2;
-            double2 *X = bufA + f * (L + SKEW);
-            for (int k = t; k <= L / 2; k += T) {
-                double2 za_c = make_double2(0.0, 0.0), zb_c = make_double2(0.0, 0.0);
-                if (k <= km) {
-                    if (k == 0) {
-                        if (ld == 0) {
-                            if (hasa) za_c.x = f0 * a0[0] + f1 * a0[azrow] + f2 * a0[2 * azrow] + f3 * a0[3 * azrow];
-                            if (hasb) zb_c.x = f0 * b0[0] + f1 * b0[azrow] + f2 * b0[2 * azrow] + f3 * b0[3 * azrow];
-                        }
-                    } else {
-                        const int bb = 2 * k - 1;
-                        if (hasa) {
-                            za_c.x = f0 * a0[bb] + f1 * a0[azrow + bb] + f2 * a0[2 * azrow + bb] + f3 * a0[3 * azrow + bb];
-                            za_c.y = f0 * a0[bb + 1] + f1 * a0[azrow + bb + 1] + f2 * a0[2 * azrow + bb + 1] + f3 * a0[3 * azrow + bb + 1];
-                        }
-                        if (hasb) {
-                            zb_c.x = f0 * b0[bb] + f1 * b0[azrow + bb] + f2 * b0[2 * azrow + bb] + f3 * b0[3 * azrow + bb];
-                            zb_c.y = f0 * b0[bb + 1] + f1 * b0[azrow + bb + 1] + f2 * b0[2 * azrow + bb + 1] + f3 * b0[3 * azrow + bb + 1];
-                        }
-                        const double2 w = phr[k];                 // e^{+ik off}
-                        za_c = cmul(za_c, w);
-                        zb_c = cmul(zb_c, w);
-                        if (ld == 1) {                            // multiply by ik
-                            za_c = make_double2(-k * za_c.y, k * za_c.x);
-                            zb_c = make_double2(-k * zb_c.y, k * zb_c.x);
-                        } else if (ld == 2) {                     // multiply by -k^2
-                            const double kk = -(double)k * k;
-                            za_c.x *= kk; za_c.y *= kk; zb_c.x *= kk; zb_c.y *= kk;
-                        }
+            const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
+            const double *a0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + za)) * K2;
+            const double *b0 = a0 + (hasb ? K2 : 0);
+#pragma unroll 2
+            for (int r = 0; r < 4; r++) {
+                const double fr = pf[r];
+                if (in1) {
+                    const double2 x = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * k1);
+                    const double2 y = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * k1);
+                    a1.x += fr * x.x; a1.y += fr * x.y; b1.x += fr * y.x; b1.y += fr * y.y;
+                }
+                if (in2) {
+                    const double2 x = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * k2);
+                    const double2 y = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * k2);
+                    a2.x += fr * x.x; a2.y += fr * x.y; b2.x += fr * y.x; b2.y += fr * y.y;
+                }
+            }
+            if (k1 == 0) { a1.y = 0.0; b1.y = 0.0; }      // block 0 is the real k = 0 coefficient, block 1 is padding
+            if (!hasb) { b1 = make_double2(0.0, 0.0); b2 = b1; }
+            a1 = cmul(a1, ph1); b1 = cmul(b1, ph1); a2 = cmul(a2, ph2); b2 = cmul(b2, ph2);
+        }
+        for (int ld = 0; ld < 3; ld++) {
+            if (!(ld == 0 ? n0 : ld == 1 ? n1 : n2)) continue;
+            const int slot = ld == 0 ? sl0 : ld == 1 ? sl1 : sl2;
+            if (active) {
+                double2 c1 = a1, e1 = b1, c2 = a2, e2 = b2;
+                if (ld == 1) {                                     // multiply by ik
+                    c1 = make_double2(-k1 * a1.y, k1 * a1.x); e1 = make_double2(-k1 * b1.y, k1 * b1.x);
+                    c2 = make_double2(-k2 * a2.y, k2 * a2.x); e2 = make_double2(-k2 * b2.y, k2 * b2.x);
+                } else if (ld == 2) {                              // multiply by -k^2
+                    const double q1 = -(double)k1 * k1, q2 = -(double)k2 * k2;
+                    c1.x *= q1; c1.y *= q1; e1.x *= q1; e1.y *= q1;
+                    c2.x *= q2; c2.y *= q2; e2.x *= q2; e2.y *= q2;
+                }
+                // W = Za + i Zb at bin k, conj(Za) + i conj(Zb) at bin L - k; Nyquist bin is zero
+                X[k1] = make_double2(c1.x - e1.y, c1.y + e1.x);
+                if (k1 > 0) X[L - k1] = make_double2(c1.x + e1.y, e1.x - c1.y);
+                else X[L / 2] = make_double2(0.0, 0.0);
+                X[k2] = make_double2(c2.x - e2.y, c2.y + e2.x);
+                X[L - k2] = make_double2(c2.x + e2.y, e2.x - c2.y);
+            }
+            wave_sync();
+            if (COPYOUT) {
+                // last pass goes back to LDS, then the whole workgroup writes full 128-byte lines
+                fft_inplace<LOGL, +1, true>(X, tw, t, active);
+                __syncthreads();
+                double *out = phys + ((int64_t)slot * V + v) * N + p0 * nz + z0;
+                {
+                    // thread -> (level zz, ring point l0 + 32 i): consecutive lanes cover the 16 levels of one point
+                    const int zz = threadIdx.x & (FZC - 1);
+                    const double *src = reinterpret_cast<const double *>(smf + (zz >> 1) * (L + SKEW)) + (zz & 1);
+                    if (zz < zc) {
+#pragma unroll 4
+                        for (int l = threadIdx.x >> 4; l < L; l += (int)(blockDim.x >> 4)) out[(int64_t)l * nz + zz] = src[2 * l];
                     }
                 }
-                // W = Za + i Zb at bin k, conj(Za) + i conj(Zb) at bin L - k
-                X[k] = make_double2(za_c.x - zb_c.y, za_c.y + zb_c.x);
-                if (k > 0 && k < L - k) X[L - k] = make_double2(za_c.x + zb_c.y, zb_c.x - za_c.y);
-            }
-        }
-        __syncthreads();
-        double2 *res = stockham_pow2<+1>(bufA, bufB, tw, L, logL, f, t, active);
-        // copy-out: full 128-byte lines (16 levels) per ring point
-        double *out = phys + ((int64_t)slot * V + v) * N + p0 * nz + z0;
-        for (int o = tid; o < L * FZC; o += FTHREADS) {
-            const int zz = o & (FZC - 1), l = o >> 4;
-            if (zz < zc) {
-                const double2 r = res[(zz >> 1) * (L + SKEW) + l];
-                out[(int64_t)l * nz + zz] = (zz & 1) ? r.y : r.x;
+                __syncthreads();
+            } else {
+                double *out = phys + ((int64_t)slot * V + v) * N + p0 * nz + z0 + za;
+                fft_inplace<LOGL, +1>(X, tw, t, active, [&](int l, double2 y) {
+                    double *o = out + (int64_t)l * nz;
+                    if (pair_ok && hasb) *reinterpret_cast<double2 *>(o) = y;
+                    else { o[0] = y.x; if (hasb) o[1] = y.y; }
+                });
+                wave_sync();      // the region is rewritten by the next slot
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ void __launch_bounds__(FTHREADS)
+template <int LOGL>
+__global__ void __launch_bounds__(512)
 k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const int *__restrict__ kmaxr,
                  const int64_t *__restrict__ pstart, const double2 *__restrict__ twg, const int64_t *__restrict__ phoff,
-                 const double2 *__restrict__ ph, int V, int nz, int K2, int64_t N, int L, int logL) {
+                 const double2 *__restrict__ ph, int V, int nz, int K2, int64_t N) {
+    constexpr int L = 1 << LOGL, T = L / 4;
     extern __shared__ double2 smf[];
     const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * FZC;
     const int zc = min(FZC, nz - z0);
     const int km = kmaxr[ring];
-    const int T = L >> 2, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int f = tid / T, t = tid - f * T;
-    const bool active = f < FNP;
-    double2 *tw = smf;
-    double2 *bufA = smf + L, *bufB = bufA + FNP * (L + SKEW);
-    for (int j = tid; j < L; j += FTHREADS) tw[j] = twg[j];
+    const int za = 2 * f, zb = 2 * f + 1;
+    const bool active = (f < FNP) && (za < zc);
+    Twiddles<LOGL> tw;
+    tw.template init<-1>(twg, t);
     const int64_t p0 = pstart[ring];
     const double *x = np1 + (int64_t)v * N + p0 * nz + z0;
-    double *ba = (double *)bufA;
-    for (int o = tid; o < L * FZC; o += FTHREADS) {
+    double *ba = (double *)smf;
+    for (int o = tid; o < L * FZC; o += blockDim.x) {
         const int zz = o & (FZC - 1), l = o >> 4;
         const double val = (zz < zc) ? x[(int64_t)l * nz + zz] : 0.0;
         ba[2 * ((zz >> 1) * (L + SKEW) + l) + (zz & 1)] = val;
     }
     __syncthreads();
-    double2 *res = stockham_pow2<-1>(bufA, bufB, tw, L, logL, f, t, active);
+    double2 *X = smf + (f < FNP ? f : 0) * (L + SKEW);
+    // forward transform; the last pass leaves the spectrum in LDS (the untangling needs bins k and L - k)
+    fft_inplace<LOGL, -1, true>(X, tw, t, active);
     if (!active) return;
-    const double2 *W = res + f * (L + SKEW);
     const double2 *phr = ph + phoff[ring];
     const double inv = 1.0 / L;
-    const int za = 2 * f, zb = 2 * f + 1;
     double *oa = Fl + (((int64_t)ring * V + v) * nz + z0 + za) * K2;
     double *ob = oa + K2;
+    const bool hasb = zb < zc;
     for (int k = t; k <= km; k += T) {
-        const double2 wk = W[k], wn = W[(L - k) & (L - 1)];
+        const double2 wk = X[k], wn = X[(L - k) & (L - 1)];
         // Xa = (W_k + conj W_{-k}) / 2,  Xb = (W_k - conj W_{-k}) / (2i)
         double2 xa = make_double2(0.5 * (wk.x + wn.x), 0.5 * (wk.y - wn.y));
         double2 xb = make_double2(0.5 * (wk.y + wn.y), -0.5 * (wk.x - wn.x));
         if (k == 0) {
-            if (za < zc) oa[0] = xa.x * inv;
-            if (zb < zc) ob[0] = xb.x * inv;
+            *reinterpret_cast<double2 *>(oa) = make_double2(xa.x * inv, 0.0);
+            if (hasb) *reinterpret_cast<double2 *>(ob) = make_double2(xb.x * inv, 0.0);
         } else {
-            const double2 w = make_double2(phr[k].x, -phr[k].y);     // e^{-ik off}
+            const double2 w = cconj(phr[k]);                        // e^{-ik off}
             xa = cmul(xa, w);
             xb = cmul(xb, w);
-            if (za < zc) { oa[2 * k - 1] = xa.x * inv; oa[2 * k] = xa.y * inv; }
-            if (zb < zc) { ob[2 * k - 1] = xb.x * inv; ob[2 * k] = xb.y * inv; }
+            *reinterpret_cast<double2 *>(oa + 2 * k) = make_double2(xa.x * inv, xa.y * inv);
+            if (hasb) *reinterpret_cast<double2 *>(ob + 2 * k) = make_double2(xb.x * inv, xb.y * inv);
         }
     }
 }
@@ -212,21 +282,46 @@ static int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
 
 bool fft_path_ok(const sx_handle *h) {
     const int L = h->uniform_L;
-    return h->has_l && L >= 16 && L <= 256 && (L & (L - 1)) == 0;   // 8 transforms x L/4 threads <= 512
+    return h->has_l && L >= 16 && L <= 256 && (L & (L - 1)) == 0;   // one transform = L/4 <= 64 lanes of one wave
 }
 
-static size_t fft_lds(int L) { return sizeof(double2) * ((size_t)L + 2 * (size_t)FNP * (L + SKEW)); }
+static size_t fft_lds(int L) { return sizeof(double2) * (size_t)FNP * (L + SKEW); }
+static int fft_threads(int L) { return std::max(64, FNP * (L / 4)); }
+
+template <int LOGL>
+static void launch_inv(sx_handle *h, const int *d_mask, dim3 g, const double *az, int64_t azrow) {
+    const int L = 1 << LOGL;
+    static const int copyout = getenv("SX_FFT_COPYOUT") ? atoi(getenv("SX_FFT_COPYOUT")) : 1;
+    if (copyout)
+        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, az, h->d_phys, h->d_phi,
+                           h->d_kmax, h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, h->nrings,
+                           h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);
+    else
+        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 0>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, az, h->d_phys, h->d_phi,
+                           h->d_kmax, h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, h->nrings,
+                           h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);
+}
+
+template <int LOGL>
+static void launch_fwd(sx_handle *h, dim3 g) {
+    const int L = 1 << LOGL;
+    hipLaunchKernelGGL(k_fl_forward_fft<LOGL>, g, dim3(fft_threads(L)), fft_lds(L), h->stream, h->d_np1, h->d_Fl, h->d_kmax,
+                       h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N);
+}
 
 void launch_rl_inverse_fft(sx_handle *h, const int *d_mask) {
     const int id = timer_id(h, "k_rl_inverse");
     timer_begin(h, id);
-    const int L = h->uniform_L;
     const double *az = h->has_z ? h->d_Az : h->d_A + (int64_t)h->cell0 * h->C;
     const int64_t azrow = h->has_z ? (int64_t)h->V * 3 * h->nz * h->K2 : h->C;
     dim3 g((h->nz + FZC - 1) / FZC, h->V, h->nrings);
-    hipLaunchKernelGGL(k_rl_inverse_fft, g, dim3(FTHREADS), fft_lds(L), h->stream, az, h->d_phys, h->d_phi, h->d_kmax,
-                       h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, h->nrings, h->N, azrow, L,
-                       ilog2(L), h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);
+    switch (ilog2(h->uniform_L)) {
+        case 4: launch_inv<4>(h, d_mask, g, az, azrow); break;
+        case 5: launch_inv<5>(h, d_mask, g, az, azrow); break;
+        case 6: launch_inv<6>(h, d_mask, g, az, azrow); break;
+        case 7: launch_inv<7>(h, d_mask, g, az, azrow); break;
+        default: launch_inv<8>(h, d_mask, g, az, azrow); break;
+    }
     HIPCHK2(hipGetLastError());
     timer_end(h);
 }
@@ -234,10 +329,14 @@ void launch_rl_inverse_fft(sx_handle *h, const int *d_mask) {
 void launch_fl_forward_fft(sx_handle *h) {
     const int id = timer_id(h, "k_fl_forward");
     timer_begin(h, id);
-    const int L = h->uniform_L;
     dim3 g((h->nz + FZC - 1) / FZC, h->V, h->nrings);
-    hipLaunchKernelGGL(k_fl_forward_fft, g, dim3(FTHREADS), fft_lds(L), h->stream, h->d_np1, h->d_Fl, h->d_kmax, h->d_pstart,
-                       h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N, L, ilog2(L));
+    switch (ilog2(h->uniform_L)) {
+        case 4: launch_fwd<4>(h, g); break;
+        case 5: launch_fwd<5>(h, g); break;
+        case 6: launch_fwd<6>(h, g); break;
+        case 7: launch_fwd<7>(h, g); break;
+        default: launch_fwd<8>(h, g); break;
+    }
     HIPCHK2(hipGetLastError());
     timer_end(h);
 }

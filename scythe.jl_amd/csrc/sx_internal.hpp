@@ -67,7 +67,8 @@ struct sx_handle {
     double xmin = 0, xmax = 0, DX = 0, l_q = 2.0, zmin = 0, zmax = 0;
     int nc = 0, V = 0, D = 0, ncoord = 1, rDim = 0, b_rDim = 0, nz = 1, Zb = 1, nsz = 1;
     int cell0 = 0, ncells = 0, nrings = 0, nbt = 0, tile_num = 0, uniform_L = 0;
-    int kDim = 0, K2 = 1, kDim_t = 0, K2t = 1, kmax_max = 0, L_max = 1;
+    int kDim = 0, K2 = 1, kDim_t = 0, K2t = 1, kmax_max = 0, L_max = 1;   // K2: device row width (padded, see sx_kernels.hip)
+    int K2ref = 1;                                                         // reference block count 1 + 2 kDim
     int64_t N = 0, Nh = 0, C = 0, S_patch = 0, S_tile = 0;
     int slot[7] = {-1, -1, -1, -1, -1, -1, -1};
     std::vector<int> hL, hkmax;

@@ -2,6 +2,7 @@
 //
 // Device data layout:
 //   spectral   A, B     [radial node m][col]            col = (v * Zb + zm) * K2 + blk   (blk fastest)
+//                       blk = 0: k = 0;  1: unused (zero);  2k: Re k;  2k+1: Im k   => (Re, Im) pairs are 16-B aligned
 //   Az                  [tile node j][v][sz][z][blk]    sz = value, d/dz, d2/dz2 (z already inverted)
 //   physical            [slot][v][point]                point = (pstart[ring] + l) * nz + z   (reference layout)
 //   var_np1, expdot_*   [v][point]
@@ -105,7 +106,7 @@ k_rl_inverse(const double *__restrict__ Az, double *__restrict__ phys, const dou
             if (k == 0) {
                 cr = f0 * a[0] + f1 * a[azrow] + f2 * a[2 * azrow] + f3 * a[3 * azrow];
             } else {
-                const int b = 2 * k - 1;
+                const int b = 2 * k;
                 cr = f0 * a[b] + f1 * a[azrow + b] + f2 * a[2 * azrow + b] + f3 * a[3 * azrow + b];
                 ci = f0 * a[b + 1] + f1 * a[azrow + b + 1] + f2 * a[2 * azrow + b + 1] + f3 * a[3 * azrow + b + 1];
                 const double2 w = phr[k];          // e^{+i k off}
@@ -181,8 +182,8 @@ k_fl_forward(const double *__restrict__ np1, double *__restrict__ Fl, const int 
             out[0] = sr * inv;
         } else {
             const double2 w = phr[k];              // multiply by e^{-i k off}
-            out[2 * k - 1] = (sr * w.x + si * w.y) * inv;
-            out[2 * k] = (si * w.x - sr * w.y) * inv;
+            out[2 * k] = (sr * w.x + si * w.y) * inv;
+            out[2 * k + 1] = (si * w.x - sr * w.y) * inv;
         }
     }
 }
