@@ -505,6 +505,96 @@ __global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgs a, int cpb) {
     for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
 }
 
+// MFMA variant of the same equation set for zDim = NZ (multiple of 16): 16 columns per workgroup. The three column
+// operators are genuine contractions  Y[NZ x 16] = M[NZ x NZ] * X[NZ x 16]  and run on the f64 matrix cores
+// (v_mfma_f64_16x16x4_f64): wave w < 12 owns (operand w / 4, row tile w % 4); A comes straight from the
+// (L2-resident) operator, B and the result tiles live in LDS, column-major with a 2-double pad (bank-conflict free).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+template <int NZ>
+__global__ void __launch_bounds__(16 * NZ) k_phys_hrbl_mfma(PhysArgs a) {
+    constexpr int CPB = 16, CS = NZ + 2;           // columns per block, column stride in LDS
+    __shared__ double X[3][CPB * CS];              // div, Kv*ubz, Kv*vbz   -> inputs
+    __shared__ double Y[3][CPB * CS];              // wb,  d/dz(...), d/dz(...) -> outputs
+    __shared__ double s1[2][CPB];                  // ub, vb at level 1 ("10 m")
+    const int k = threadIdx.x % NZ, cl = threadIdx.x / NZ;
+    const int64_t ncol = a.N / NZ;
+    const int64_t col = (int64_t)blockIdx.x * CPB + cl;
+    const bool live = col < ncol;
+    const double *par = a.par;
+    const double g = par[SX_P_G], Kh = par[SX_P_KH], Hfree = par[SX_P_HFREE], f = par[SX_P_F];
+    const int64_t p = live ? col * NZ + k : 0;
+    double r = 1.0, h = 0, hr = 0, hl = 0, ug = 0, ugr = 0, ugl = 0, vg = 0, vgr = 0, vgl = 0;
+    double ub = 0, ubr = 0, ubrr = 0, ubl = 0, ubll = 0, ubz = 0, vb = 0, vbr = 0, vbrr = 0, vbl = 0, vbll = 0, vbz = 0;
+    double xd = 0.0, xu = 0.0, xv = 0.0;
+    if (live) {
+        r = a.r[col];
+        h = PS(0, a.s_u); hr = PS(0, a.s_r); hl = PS(0, a.s_l);
+        ug = PS(1, a.s_u); ugr = PS(1, a.s_r); ugl = PS(1, a.s_l);
+        vg = PS(2, a.s_u); vgr = PS(2, a.s_r); vgl = PS(2, a.s_l);
+        ub = PS(3, a.s_u); ubr = PS(3, a.s_r); ubrr = PS(3, a.s_rr); ubl = PS(3, a.s_l); ubll = PS(3, a.s_ll); ubz = PS(3, a.s_z);
+        vb = PS(4, a.s_u); vbr = PS(4, a.s_r); vbrr = PS(4, a.s_rr); vbl = PS(4, a.s_l); vbll = PS(4, a.s_ll); vbz = PS(4, a.s_z);
+        const double S = sqrt((ubz * ubz) + (vbz * vbz));
+        const double l = 1.0 / ((1.0 / (0.4 * a.z[k])) + (1.0 / 80.0));
+        const double Kv = (l * l) * S;
+        xd = -((ub / r) + ubr + (vbl / r));
+        xu = Kv * ubz;
+        xv = Kv * vbz;
+        if (k == 1) { s1[0][cl] = ub; s1[1][cl] = vb; }
+    }
+    __syncthreads();
+    if (live && k == 0) {
+        const double Um = par[SX_P_UM], Vm = par[SX_P_VM];
+        const double cs = a.cosl[col], sn = a.sinl[col];
+        const double sfcu = (Um * cs) + (Vm * sn), sfcv = (Vm * cs) - (Um * sn);
+        const double u10 = s1[0][cl] + sfcu, v10 = s1[1][cl] + sfcv;
+        const double U10 = sqrt(u10 * u10 + v10 * v10);
+        double Cd = par[SX_P_CD];
+        if (U10 < 5.2) Cd = 1.0e-3;
+        else if (U10 < 33.6) Cd = 4.4e-4 * sqrt(U10);
+        xu = Cd * U10 * u10;
+        xv = Cd * U10 * v10;
+    }
+    X[0][cl * CS + k] = xd;
+    X[1][cl * CS + k] = xu;
+    X[2][cl * CS + k] = xv;
+    __syncthreads();
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        constexpr int RT = NZ / 16;                 // row tiles per operand
+        if (wave < 3 * RT) {
+            const int op = wave / RT, rt = wave % RT;
+            const double *MT = (op == 0) ? a.MintT : a.MdzT;      // MT[j][k] = M[k][j]
+            const double *xb = X[op] + (lane & 15) * CS + (lane >> 4);
+            const double *ma = MT + (int64_t)(lane >> 4) * NZ + rt * 16 + (lane & 15);
+            mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+            for (int ks = 0; ks < NZ / 4; ks++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[(int64_t)ks * 4 * NZ], xb[ks * 4], acc, 0, 0, 0);
+            double *yo = Y[op] + (lane & 15) * CS + rt * 16 + (lane >> 4);
+            yo[0] = acc[0]; yo[4] = acc[1]; yo[8] = acc[2]; yo[12] = acc[3];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    const double wb = Y[0][cl * CS + k], vdu = Y[1][cl * CS + k], vdv = Y[2][cl * CS + k];
+    a.physw[((int64_t)a.s_u * a.V + 5) * a.N + p] = wb;
+    const double e0 = ((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)));
+    const double e1 = ((-vg * ugl / r) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg / r)));
+    const double e2 = ((-vg * vgl / r) + (-ug * vgr)) + (-g * (hl / r)) + (-ug * (f + (vg / r)));
+    const double e3 = ((-vb * ubl / r) + (-ub * ubr) + (-wb * ubz)) + (-g * hr) + (vb * (f + (vb / r))) + vdu +
+                      (Kh * ((ubr / r) + ubrr - (ub / (r * r)) + (ubll / (r * r)) - (2.0 * vbl / (r * r))));
+    const double e4 = ((-vb * vbl / r) + (-ub * vbr) + (-wb * vbz)) + (-g * (hl / r)) + (-ub * (f + (vb / r))) + vdv +
+                      (Kh * ((vbr / r) + vbrr - (vb / (r * r)) + (vbll / (r * r)) + (2.0 * ubl / (r * r))));
+    ab_step(a, 0, p, h, e0);
+    ab_step(a, 1, p, ug, e1);
+    ab_step(a, 2, p, vg, e2);
+    ab_step(a, 3, p, ub, e3);
+    ab_step(a, 4, p, vb, e4);
+    ab_step(a, 5, p, wb, 0.0);
+    for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+}
+
 // semiimplicit_adjustment (src/semiimplicit.jl:521-597), one workgroup per group of columns
 struct SemiArgs {
     double *np1;
@@ -624,7 +714,14 @@ static PhysArgs phys_args(sx_handle *h, int t) {
 void launch_physics(sx_handle *h, int t) {
     if (h->eq != SX_EQ_NONE && t == 1) h->rot = 0;
     PhysArgs a = phys_args(h, t);
-    if (h->eq == SX_EQ_ONEWAY_SW_HRBL) {
+    if (h->eq == SX_EQ_ONEWAY_SW_HRBL && (h->nz == 64 || h->nz == 32)) {
+        const int id = timer_id(h, "k_phys_hrbl");
+        timer_begin(h, id);
+        if (h->nz == 64) hipLaunchKernelGGL(k_phys_hrbl_mfma<64>, grid1(h->Nh, 16), dim3(1024), 0, h->stream, a);
+        else hipLaunchKernelGGL(k_phys_hrbl_mfma<32>, grid1(h->Nh, 16), dim3(512), 0, h->stream, a);
+        HIPCHK(hipGetLastError());
+        timer_end(h);
+    } else if (h->eq == SX_EQ_ONEWAY_SW_HRBL) {
         const int id = timer_id(h, "k_phys_hrbl");
         timer_begin(h, id);
         const int cpb = h->nz >= 256 ? 1 : 256 / h->nz;

@@ -59,6 +59,12 @@ def test_rlz_hrbl_fft_rings(ring_L, zDim, cells):
     assert _run(cases.rlz_hrbl(num_cells=cells, zDim=zDim, ring_L=ring_L), 3) < TOL
 
 
+@pytest.mark.parametrize("zDim", [64, 32])
+def test_rlz_hrbl_mfma_column_operators(zDim):
+    """zDim 64 / 32 take the f64-MFMA column-operator kernel (16 columns per workgroup, ragged last block)."""
+    assert _run(cases.rlz_hrbl(num_cells=3, zDim=zDim, ring_L=16), 3) < TOL
+
+
 def test_rl_slab_fft_rings():
     assert _run(cases.rl_slab(ring_L=64), 4) < TOL
 
