@@ -390,6 +390,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         const int nb = h->b_rDim;
         std::vector<int> cmeta((size_t)h->ncls * 4);
         std::vector<double> gl((size_t)h->ncls * 6), gr((size_t)h->ncls * 6), Lb((size_t)h->ncls * nb * 4), La((size_t)h->ncls * 3 * nb);
+        std::vector<double> Ldinv((size_t)h->ncls * nb, 0.0);
         for (int c = 0; c < h->ncls; c++) {
             const SplineClass &s = classes[c];
             cmeta[c * 4 + 0] = s.nfree; cmeta[c * 4 + 1] = s.periodic; cmeta[c * 4 + 2] = s.rl; cmeta[c * 4 + 3] = s.rr;
@@ -397,9 +398,10 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
                 for (int j = 0; j < 2; j++) { gl[c * 6 + i * 2 + j] = s.gl[i][j]; gr[c * 6 + i * 2 + j] = s.gr[i][j]; }
             std::copy(s.Lband.begin(), s.Lband.end(), Lb.begin() + (size_t)c * nb * 4);
             std::copy(s.Larrow.begin(), s.Larrow.end(), La.begin() + (size_t)c * 3 * nb);
+            for (int i = 0; i < s.nfree; i++) Ldinv[(size_t)c * nb + i] = 1.0 / s.Lband[(size_t)i * 4 + 3];
         }
         if (!upload(h, &h->d_cls, cls) || !upload(h, &h->d_cmeta, cmeta) || !upload(h, &h->d_gl, gl) || !upload(h, &h->d_gr, gr) ||
-            !upload(h, &h->d_Lband, Lb) || !upload(h, &h->d_Larrow, La))
+            !upload(h, &h->d_Lband, Lb) || !upload(h, &h->d_Larrow, La) || !upload(h, &h->d_Ldinv, Ldinv))
             FAIL();
     }
 

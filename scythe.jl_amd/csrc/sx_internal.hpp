@@ -95,7 +95,7 @@ struct sx_handle {
     double *d_WT[2] = {}, *d_XT[2] = {};
     double tau[2] = {0, 0};
     int *d_cls = nullptr, *d_cmeta = nullptr;   // cmeta [ncls][4] = nfree, periodic, rl, rr
-    double *d_gl = nullptr, *d_gr = nullptr, *d_Lband = nullptr, *d_Larrow = nullptr;
+    double *d_gl = nullptr, *d_gr = nullptr, *d_Lband = nullptr, *d_Larrow = nullptr, *d_Ldinv = nullptr;
     double *d_r = nullptr, *d_cosl = nullptr, *d_sinl = nullptr, *d_z = nullptr;
     int *d_flag = nullptr;
     int *d_mask_full = nullptr, *d_mask_eq = nullptr;   // per-variable bit masks of derivative slots to produce

@@ -35,8 +35,9 @@ __global__ void __launch_bounds__(256)
 k_colmat(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ mats,
          const ColJob *__restrict__ jobs, int n_in, int n_out, int K2, int64_t in_row, int64_t out_row, int row0) {
     extern __shared__ double As[];
-    const int lane = threadIdx.x, g = threadIdx.y;
-    const int blk = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.y);     // blockDim.x == 64: one wave per g => operator
+    const int blk = blockIdx.x * 64 + lane;                         // entries become scalar loads
     const ColJob job = jobs[blockIdx.y];
     const double *src = in + (int64_t)(row0 + blockIdx.z) * in_row + job.in_off;
     double *dst = out + (int64_t)blockIdx.z * out_row + job.out_off;
@@ -209,18 +210,32 @@ __global__ void k_sb(const double *__restrict__ Fl, double *__restrict__ Bz, con
 // ------------------------------------------------------------------------------------------------ B -> A banded SPD solve
 // One lane per right-hand side (column); rows are contiguous across lanes so every load/store is coalesced.
 // a = Gamma^T (L L^T)^-1 Gamma b with L banded (half-bandwidth 3) plus, for PERIODIC, three dense last rows.
-__global__ void __launch_bounds__(256)
+// A wave covers 64 consecutive wavenumber blocks of one (variable, z-mode): its boundary-condition class is
+// wave-uniform, so the factor entries are scalar loads. The k = 0 column (its own class) is handled by one extra
+// block per (variable, z-mode) in which only lane 0 works.
+#define SOLVE_U 8      // rows whose right-hand sides are fetched ahead of the dependent substitution chain
+__global__ void __launch_bounds__(64)
 k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, double *__restrict__ A,
         const int *__restrict__ cls, const int *__restrict__ cmeta, const double *__restrict__ gl,
-        const double *__restrict__ gr, const double *__restrict__ Lband, const double *__restrict__ Larrow, int nb,
-        int Zb, int K2, int64_t C) {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= C) return;
-    const int blk = (int)(col % K2);
-    const int v = (int)(col / ((int64_t)Zb * K2));
-    const int c = cls[v * 2 + (blk == 0 ? 0 : 1)];
+        const double *__restrict__ gr, const double *__restrict__ Lband, const double *__restrict__ Ldinv,
+        const double *__restrict__ Larrow, int nb, int Zb, int K2) {
+    const int vz = blockIdx.y;                      // (v, zm)
+    const int v = vz / Zb;
+    const int k0 = (blockIdx.x == gridDim.x - 1);   // the last block in x handles the k = 0 column
+    int blk;
+    if (k0) {
+        blk = 0;
+        if (threadIdx.x != 0) return;
+    } else {
+        blk = blockIdx.x * 64 + threadIdx.x;
+        if (blk >= K2 || (K2 > 1 && blk < 2)) return;            // block 0 -> k0 launch, block 1 is padding (stays zero)
+    }
+    const int64_t C = (int64_t)gridDim.y * K2;
+    const int64_t col = (int64_t)vz * K2 + blk;
+    const int c = cls[v * 2 + (k0 ? 0 : 1)];
     const int n = cmeta[c * 4 + 0], per = cmeta[c * 4 + 1], rl = cmeta[c * 4 + 2], rr = cmeta[c * 4 + 3];
     const double *Lb = Lband + (int64_t)c * nb * 4;
+    const double *Ld = Ldinv + (int64_t)c * nb;
     const double *La = Larrow + (int64_t)c * 3 * nb;
     const double *g_l = gl + c * 6, *g_r = gr + c * 6;
 #define BROW(m) Bsrc[rowoff[m] + col]
@@ -228,31 +243,55 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, dou
     if (!per) {
         // forward substitution; the free unknown i lives in row rl + i of A
         double y1 = 0.0, y2 = 0.0, y3 = 0.0;     // y[i-1], y[i-2], y[i-3]
-        for (int i = 0; i < n; i++) {
-            double s = BROW(rl + i);
-            if (i < 2) for (int q = 0; q < rl; q++) s += g_l[q * 2 + i] * BROW(q);
-            if (i >= n - 2) for (int q = 0; q < rr; q++) s += g_r[q * 2 + (n - 1 - i)] * BROW(nb - 1 - q);
-            const double *l = Lb + (int64_t)i * 4;
-            s -= l[2] * y1 + l[1] * y2 + l[0] * y3;
-            s /= l[3];
-            y3 = y2; y2 = y1; y1 = s;
-            AROW(rl + i) = s;
+        double bl0 = 0.0, bl1 = 0.0;
+        for (int q = 0; q < rl; q++) { const double bq = BROW(q); bl0 += g_l[q * 2] * bq; bl1 += g_l[q * 2 + 1] * bq; }
+        double br0 = 0.0, br1 = 0.0;
+        for (int q = 0; q < rr; q++) { const double bq = BROW(nb - 1 - q); br0 += g_r[q * 2] * bq; br1 += g_r[q * 2 + 1] * bq; }
+        for (int i0 = 0; i0 < n; i0 += SOLVE_U) {
+            double rhs[SOLVE_U];
+#pragma unroll
+            for (int u = 0; u < SOLVE_U; u++) rhs[u] = (i0 + u < n) ? BROW(rl + i0 + u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < SOLVE_U; u++) {
+                const int i = i0 + u;
+                if (i < n) {
+                    double s = rhs[u];
+                    if (i == 0) s += bl0;
+                    if (i == 1) s += bl1;
+                    if (i == n - 1) s += br0;
+                    if (i == n - 2) s += br1;
+                    const double *l = Lb + (int64_t)i * 4;
+                    s -= l[2] * y1 + l[1] * y2 + l[0] * y3;
+                    s *= Ld[i];
+                    y3 = y2; y2 = y1; y1 = s;
+                    AROW(rl + i) = s;
+                }
+            }
         }
         // back substitution
         double x1 = 0.0, x2 = 0.0, x3 = 0.0;     // x[i+1], x[i+2], x[i+3]
         double xl0 = 0.0, xl1 = 0.0, xr0 = 0.0, xr1 = 0.0;
-        for (int i = n - 1; i >= 0; i--) {
-            double s = AROW(rl + i);
-            if (i + 1 < n) s -= Lb[(int64_t)(i + 1) * 4 + 2] * x1;
-            if (i + 2 < n) s -= Lb[(int64_t)(i + 2) * 4 + 1] * x2;
-            if (i + 3 < n) s -= Lb[(int64_t)(i + 3) * 4 + 0] * x3;
-            s /= Lb[(int64_t)i * 4 + 3];
-            x3 = x2; x2 = x1; x1 = s;
-            AROW(rl + i) = s;
-            if (i == n - 1) xr0 = s;
-            if (i == n - 2) xr1 = s;
-            if (i == 1) xl1 = s;
-            if (i == 0) xl0 = s;
+        for (int i0 = n - 1; i0 >= 0; i0 -= SOLVE_U) {
+            double rhs[SOLVE_U];
+#pragma unroll
+            for (int u = 0; u < SOLVE_U; u++) rhs[u] = (i0 - u >= 0) ? AROW(rl + i0 - u) : 0.0;
+#pragma unroll
+            for (int u = 0; u < SOLVE_U; u++) {
+                const int i = i0 - u;
+                if (i >= 0) {
+                    double s = rhs[u];
+                    if (i + 1 < n) s -= Lb[(int64_t)(i + 1) * 4 + 2] * x1;
+                    if (i + 2 < n) s -= Lb[(int64_t)(i + 2) * 4 + 1] * x2;
+                    if (i + 3 < n) s -= Lb[(int64_t)(i + 3) * 4 + 0] * x3;
+                    s *= Ld[i];
+                    x3 = x2; x2 = x1; x1 = s;
+                    AROW(rl + i) = s;
+                    if (i == n - 1) xr0 = s;
+                    if (i == n - 2) xr1 = s;
+                    if (i == 1) xl1 = s;
+                    if (i == 0) xl0 = s;
+                }
+            }
         }
         for (int q = 0; q < rl; q++) AROW(q) = g_l[q * 2] * xl0 + g_l[q * 2 + 1] * xl1;
         for (int q = 0; q < rr; q++) AROW(nb - 1 - q) = g_r[q * 2] * xr0 + g_r[q * 2 + 1] * xr1;
@@ -266,7 +305,7 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, dou
             if (i == 1) s += BROW(nb - 1);
             const double *l = Lb + (int64_t)i * 4;
             s -= l[2] * y1 + l[1] * y2 + l[0] * y3;
-            s /= l[3];
+            s *= Ld[i];
             y3 = y2; y2 = y1; y1 = s;
             AROW(i + 1) = s;
             acc0 += La[i] * s;
@@ -291,7 +330,7 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, dou
             if (i + 2 < n - 3) s -= Lb[(int64_t)(i + 2) * 4 + 1] * x2;
             if (i + 3 < n - 3) s -= Lb[(int64_t)(i + 3) * 4 + 0] * x3;
             s -= La[i] * u0 + La[nb + i] * u1 + La[2 * nb + i] * u2;
-            s /= Lb[(int64_t)i * 4 + 3];
+            s *= Ld[i];
             x3 = x2; x2 = x1; x1 = s;
             AROW(i + 1) = s;
             if (i == 0) first0 = s;
@@ -794,8 +833,9 @@ void launch_zf(sx_handle *h) {
 void launch_solve(sx_handle *h) {
     const int id = timer_id(h, "k_solve");
     timer_begin(h, id);
-    hipLaunchKernelGGL(k_solve, grid1(h->C, 256), dim3(256), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_A, h->d_cls,
-                       h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Larrow, h->b_rDim, h->Zb, h->K2, h->C);
+    dim3 g((h->K2 > 1 ? (h->K2 + 63) / 64 : 0) + 1, h->V * h->Zb);
+    hipLaunchKernelGGL(k_solve, g, dim3(64), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_A, h->d_cls, h->d_cmeta, h->d_gl,
+                       h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2);
     HIPCHK(hipGetLastError());
     timer_end(h);
 }
