@@ -8,8 +8,9 @@ One "step" is one pass of model_loop's body (src/semiimplicit.jl:268-297): tileT
 (Oneway_ShallowWater_HeightResolvedBL) -> explicit_timestep -> spectralTransform! -> halo/sum -> splineTransform!.
 Workload (SURVEY.md 8(d) "perf shape"): 171 radial cells -> 513 rings x 256 azimuthal points x 64 Chebyshev levels,
 6 variables, 7 derivative slots, fp64, synthetic vortex initial condition resident in HBM before the timed region.
-For N > 1 the 171 cells are split into N radial tiles, one per GPU (strong scaling), with the halo sent rank -> rank+1
-and the owned B rows all-gathered over RCCL.
+For N > 1 the 171 cells are split into N radial tiles, one per GPU (strong scaling); the patch-level B -> A solve is
+transposed across the GPUs with two RCCL all-to-alls per step (--exchange gather selects the reference's protocol:
+halo rank -> rank+1, all-gather of owned rows, redundant patch solve).
 
 Prints ONE JSON line on rank 0 with the driver's contract plus "roofline" (dominant kernel, live hipEvent timing) and
 "cpu_baseline" (the C oracle "port" on a bounded radial sample of the same workload, rank 0, N = 1 only).
@@ -94,6 +95,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="rlz_513x256x64", choices=sorted(WORKLOADS))
+    ap.add_argument("--exchange", default="a2a", choices=["a2a", "gather"],
+                    help="multi-GPU patch solve: transposed all-to-all (default) or the reference's halo + gather protocol")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=18)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -120,7 +123,8 @@ def main():
     gp = S.GridParameters(ring_uniform_L=L, **kw)
     mp = S.ModelParameters(ts=TS, equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
                            physical_params=dict(PAR))
-    run = S.ModelRun(mp, num_tiles=world, rank=rank, device=torch.device("cuda", local_rank), use_dist=world > 1)
+    run = S.ModelRun(mp, num_tiles=world, rank=rank, device=torch.device("cuda", local_rank), use_dist=world > 1,
+                     exchange=args.exchange)
     tile = run.tiles[0]
     pts = S.getGridpoints(tile)
     run.set_initial_conditions([initial_condition(pts)])
@@ -175,7 +179,7 @@ def main():
             "config": {"workload": "RLZ %dx%dx%d (rings x azimuth x levels), 6 vars, 7 derivative slots, "
                                    "Oneway_ShallowWater_HeightResolvedBL, uniform ring table kmax<=%d, b_zDim %d"
                                    % (3 * nc, L, nz, L // 2 - 1, int(tile.dims.b_zDim)),
-                       "num_cells": nc, "tiles": world, "ts": TS, "nan": bool(nan)},
+                       "num_cells": nc, "tiles": world, "exchange": run.exchange_kind, "ts": TS, "nan": bool(nan)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},

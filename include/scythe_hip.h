@@ -171,6 +171,23 @@ int sx_bind_patch_b(sx_handle *h, const void *dev_base, const int64_t *row_offse
 /* device pointer of the patch A array [b_rDim][n_cols] */
 int sx_patch_a_device(sx_handle *h, void **dev_ptr, int64_t *n_rows, int64_t *n_cols);
 
+/* --- transposed (all-to-all) patch solve -----------------------------------------------------------------------------
+ * Scalable alternative to halo + all-gather + redundant solve (src/semiimplicit.jl:320-329, 285) for n tiles = n GPUs.
+ * The columns of the [node][col] arrays are split into n contiguous ranges of whole (variable, z-mode) groups
+ * (sx_a2a_col_starts). Per step, after sx_advance:
+ *   1. sx_a2a_pack_b      tile B rows -> send buffer [dest d][row j < tile_b_rDim][cols of d]
+ *   2. all-to-all         every tile's rows for my columns arrive as [tile t][row j][my cols]
+ *   3. sx_a2a_solve       sums the rows two tiles share (the reference's halo add), solves my columns for the whole
+ *                         patch, writes the solution rows back in the same [tile t][row j][my cols] layout
+ *   4. all-to-all         reverse direction
+ *   5. sx_a2a_unpack_a    [owner d][row j][cols of d] -> the patch A rows this tile evaluates
+ * tile_cell0 / tile_num_cells describe all n tiles (calcTileSizes rows 4 and 3, 0-based cell0). */
+int sx_a2a_configure(sx_handle *h, int32_t n_tiles, int32_t my_tile, const int32_t *tile_cell0, const int32_t *tile_num_cells);
+int sx_a2a_col_starts(sx_handle *h, int64_t *out /* [n_tiles + 1] */);
+int sx_a2a_pack_b(sx_handle *h, void *dev_send);
+int sx_a2a_solve(sx_handle *h, const void *dev_recv, void *dev_send);
+int sx_a2a_unpack_a(sx_handle *h, const void *dev_recv);
+
 /* --- measurement ---------------------------------------------------------------------------------------------------- */
 /* hipEvent timers around every kernel on the handle's stream (off by default). */
 int sx_enable_timers(sx_handle *h, int32_t on);

@@ -4,5 +4,6 @@ The directory name contains a dot, so import it through the `scythe_jl_amd` shim
 from ._lib import load, ScytheHipError, LIB_PATH
 from .model import (CubicBSpline, Chebyshev, GridParameters, ModelParameters, Grid, createGrid, getGridpoints,
                     calcTileSizes, num_columns, checkCFL)
-from .driver import PatchLayout, LocalExchange, DistExchange, ModelRun, integrate_model
+from .driver import (PatchLayout, LocalExchange, DistExchange, A2ALayout, LocalA2AExchange, DistA2AExchange, ModelRun,
+                     integrate_model)
 from .io import read_physical_grid, write_output

@@ -69,6 +69,11 @@ SYMBOLS = {
     "sx_halo_add": (C.c_int, [_H, C.c_void_p]),
     "sx_bind_patch_b": (C.c_int, [_H, C.c_void_p, P_I64]),
     "sx_patch_a_device": (C.c_int, [_H, C.POINTER(C.c_void_p), P_I64, P_I64]),
+    "sx_a2a_configure": (C.c_int, [_H, C.c_int32, C.c_int32, P_I32, P_I32]),
+    "sx_a2a_col_starts": (C.c_int, [_H, P_I64]),
+    "sx_a2a_pack_b": (C.c_int, [_H, C.c_void_p]),
+    "sx_a2a_solve": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "sx_a2a_unpack_a": (C.c_int, [_H, C.c_void_p]),
     "sx_enable_timers": (C.c_int, [_H, C.c_int32]),
     "sx_reset_timers": (C.c_int, [_H]),
     "sx_get_timers": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_char_p), P_D, P_I64, P_I32]),

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <type_traits>
 
 namespace sx {
 
@@ -439,7 +440,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     // ---- state
     const int64_t C = h->C, N = h->N;
     if (!dalloc(h, &h->d_A, (size_t)h->b_rDim * C) || !dalloc(h, &h->d_Bfull, (size_t)h->b_rDim * C) ||
-        !dalloc(h, &h->d_rowoff, (size_t)h->b_rDim) || !dalloc(h, &h->d_phys, (size_t)h->D * h->V * N) ||
+        !dalloc(h, &h->d_rowoff, (size_t)h->b_rDim) || !dalloc(h, &h->d_aoff, (size_t)h->b_rDim) || !dalloc(h, &h->d_neg1, (size_t)h->b_rDim) || !dalloc(h, &h->d_phys, (size_t)h->D * h->V * N) ||
         !dalloc(h, &h->d_np1, (size_t)h->V * N) || !dalloc(h, &h->d_flag, 1))
         FAIL();
     for (int i = 0; i < 3; i++) {
@@ -504,6 +505,15 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
             h->njobs_zinv_full = (int)jf.size();
             h->njobs_zinv_eq = (int)je.size();
             if (!upload(h, &h->d_jobs_zinv_full, jf) || !upload(h, &h->d_jobs_zinv_eq, je) || !upload(h, &h->d_jobs_zf, jz)) FAIL();
+        }
+    }
+    {
+        std::vector<int64_t> ao(h->b_rDim), neg(h->b_rDim, -1);
+        for (int m = 0; m < h->b_rDim; m++) ao[m] = (int64_t)m * h->C;
+        if (hipMemcpy(h->d_aoff, ao.data(), sizeof(int64_t) * ao.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(h->d_neg1, neg.data(), sizeof(int64_t) * neg.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("hipMemcpy H2D failed");
+            FAIL();
         }
     }
     if (sx_bind_patch_b(h, nullptr, nullptr)) FAIL();
@@ -754,6 +764,87 @@ int sx_patch_a_device(sx_handle *h, void **p, int64_t *rows, int64_t *cols) {
     return 0;
 }
 
+// ---- transposed (all-to-all) patch solve ---------------------------------------------------------------------------
+int sx_a2a_configure(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells) {
+    clear_error();
+    if (!h || !cell0 || !ncells || n < 1 || me < 0 || me >= n) { set_error("invalid argument"); return 1; }
+    if (cell0[me] != h->cell0 || ncells[me] != h->ncells) { set_error("tile table does not match this handle"); return 1; }
+    int c = 0;
+    for (int t = 0; t < n; t++) {
+        if (cell0[t] != c || ncells[t] < 3) { set_error("tiles must be contiguous with at least 3 cells each"); return 1; }
+        c += ncells[t];
+    }
+    if (c != h->nc) { set_error("tiles do not cover the patch"); return 1; }
+    h->a2a_n = n; h->a2a_me = me;
+    h->a2a_cell0.assign(cell0, cell0 + n);
+    h->a2a_ncells.assign(ncells, ncells + n);
+    const int G = h->V * h->Zb;                               // column groups (variable, z-mode), K2 columns each
+    std::vector<int> owner(G);
+    std::vector<int64_t> cs(n + 1), cw(n), soff(n);
+    for (int d = 0; d <= n; d++) cs[d] = (int64_t)((int64_t)G * d / n) * h->K2;
+    for (int d = 0; d < n; d++) {
+        cw[d] = cs[d + 1] - cs[d];
+        for (int64_t g = cs[d] / h->K2; g < cs[d + 1] / h->K2; g++) owner[g] = d;
+    }
+    // tile-side buffers: [dest d][row j < nbt][cw[d]]
+    int64_t o = 0;
+    for (int d = 0; d < n; d++) { soff[d] = o; o += (int64_t)h->nbt * cw[d]; }
+    h->a2a_colstart = cs;
+    h->a2a_g0 = (int)(cs[me] / h->K2);
+    h->a2a_g1 = (int)(cs[me + 1] / h->K2);
+    // owner-side buffers: [tile t][row j < ncells[t] + 3][cw[me]]; row m of the patch lives in its owning tile and, for the
+    // first three rows of tiles t >= 1, also in the previous tile (its halo rows)
+    std::vector<int64_t> offA(h->b_rDim, 0), offB(h->b_rDim, -1), tbase(n);
+    o = 0;
+    for (int t = 0; t < n; t++) { tbase[t] = o; o += (int64_t)(ncells[t] + 3) * cw[me]; }
+    for (int t = 0; t < n; t++) {
+        const int owned = ncells[t] + (t == n - 1 ? 3 : 0);
+        for (int j = 0; j < owned; j++) offA[cell0[t] + j] = tbase[t] + (int64_t)j * cw[me];
+        if (t > 0)
+            for (int j = 0; j < 3; j++) offB[cell0[t] + j] = tbase[t - 1] + (int64_t)(ncells[t - 1] + j) * cw[me];
+    }
+    auto up = [&](auto **p, const auto &v) {
+        using T = typename std::remove_reference<decltype(v)>::type::value_type;
+        if (!*p && !dalloc(h, p, v.size(), false)) return false;
+        return hipMemcpy(*p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    std::vector<int64_t> csn(cs.begin(), cs.begin() + n);
+    if (!up(&h->d_a2a_owner, owner) || !up(&h->d_a2a_soff, soff) || !up(&h->d_a2a_cw, cw) || !up(&h->d_a2a_cs, csn) ||
+        !up(&h->d_a2a_offA, offA) || !up(&h->d_a2a_offB, offB)) {
+        set_error("a2a table upload failed");
+        return 1;
+    }
+    return status();
+}
+
+int sx_a2a_col_starts(sx_handle *h, int64_t *out) {
+    clear_error();
+    if (!h || !out || h->a2a_n < 1) { set_error("sx_a2a_configure has not been called"); return 1; }
+    for (int d = 0; d <= h->a2a_n; d++) out[d] = h->a2a_colstart[d];
+    return 0;
+}
+
+int sx_a2a_pack_b(sx_handle *h, void *dev_send) {
+    clear_error();
+    if (!h || !dev_send || h->a2a_n < 1) { set_error("invalid argument / not configured"); return 1; }
+    launch_a2a_pack(h, (double *)dev_send, 0);
+    return status();
+}
+
+int sx_a2a_solve(sx_handle *h, const void *dev_recv, void *dev_send) {
+    clear_error();
+    if (!h || !dev_recv || !dev_send || h->a2a_n < 1) { set_error("invalid argument / not configured"); return 1; }
+    launch_solve_a2a(h, (const double *)dev_recv, (double *)dev_send);
+    return status();
+}
+
+int sx_a2a_unpack_a(sx_handle *h, const void *dev_recv) {
+    clear_error();
+    if (!h || !dev_recv || h->a2a_n < 1) { set_error("invalid argument / not configured"); return 1; }
+    launch_a2a_pack(h, (double *)const_cast<void *>(dev_recv), 1);
+    return status();
+}
+
 int sx_enable_timers(sx_handle *h, int32_t on) {
     clear_error();
     if (!h) { set_error("null handle"); return 1; }
@@ -800,7 +891,12 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     (void)D;
     if (k == "k_rl_inverse") b = w * (N * planes + az);             // write the requested physical planes, read Az
     else if (k == "k_zinv") b = w * (S_tile + az);
-    else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") b = w * N * (h->mask_eq_bits + 4.0 * V);  // read slots, E_nm1, E_nm2; write E_n, var_np1
+    else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") {
+        // read the requested slots, E_nm1, E_nm2; write E_n, var_np1; the SW sets also write the diagnostic w plane and
+        // keep no tendency history for it
+        const bool sw = (h->eq == SX_EQ_ONEWAY_SW_SLAB || h->eq == SX_EQ_TWOWAY_SW_SLAB || h->eq == SX_EQ_ONEWAY_SW_HRBL);
+        b = w * N * (h->mask_eq_bits + 4.0 * V + (sw ? 1.0 - 3.0 : 0.0));
+    }
     else if (k == "k_fl_forward") b = w * (N * V + fl);
     else if (k == "k_sb") b = w * (fl + bz);
     else if (k == "k_zf") b = w * (bz + S_tile);

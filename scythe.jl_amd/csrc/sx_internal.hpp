@@ -84,7 +84,13 @@ struct sx_handle {
     hipStream_t stream = nullptr;
     double *d_A = nullptr, *d_Bfull = nullptr, *d_Btile = nullptr, *d_Btile_own = nullptr;
     const double *d_Bsrc = nullptr;
-    int64_t *d_rowoff = nullptr;
+    int64_t *d_rowoff = nullptr, *d_aoff = nullptr, *d_neg1 = nullptr;
+    // transposed (all-to-all) solve
+    int a2a_n = 0, a2a_me = 0, a2a_g0 = 0, a2a_g1 = 0;
+    std::vector<int64_t> a2a_colstart;          // [n + 1] column (not group) starts
+    std::vector<int> a2a_cell0, a2a_ncells;
+    int *d_a2a_owner = nullptr;
+    int64_t *d_a2a_soff = nullptr, *d_a2a_cw = nullptr, *d_a2a_cs = nullptr, *d_a2a_offA = nullptr, *d_a2a_offB = nullptr;
     double *d_Az = nullptr, *d_phys = nullptr, *d_np1 = nullptr, *d_E[3] = {}, *d_I[3] = {};
     double *d_Fl = nullptr, *d_Bz = nullptr;
     double *d_phi = nullptr, *d_wq = nullptr;
@@ -126,6 +132,8 @@ void launch_fl_forward(sx_handle *h);
 void launch_sb(sx_handle *h);
 void launch_zf(sx_handle *h);
 void launch_solve(sx_handle *h);
+void launch_solve_a2a(sx_handle *h, const double *recv, double *send);
+void launch_a2a_pack(sx_handle *h, double *buf, int unpack);
 void launch_halo_add(sx_handle *h, const double *recv);
 void launch_nan_check(sx_handle *h);
 int timer_id(sx_handle *h, const char *name);

@@ -213,14 +213,24 @@ __global__ void k_sb(const double *__restrict__ Fl, double *__restrict__ Bz, con
 // A wave covers 64 consecutive wavenumber blocks of one (variable, z-mode): its boundary-condition class is
 // wave-uniform, so the factor entries are scalar loads. The k = 0 column (its own class) is handled by one extra
 // block per (variable, z-mode) in which only lane 0 works.
-#define SOLVE_U 8      // rows whose right-hand sides are fetched ahead of the dependent substitution chain
+#define SOLVE_U 8
+__device__ __forceinline__ double brow(const double *__restrict__ B, const int64_t *__restrict__ oa,
+                                       const int64_t *__restrict__ ob, int m, int64_t col) {
+    double x = B[oa[m] + col];
+    const int64_t o2 = ob[m];
+    if (o2 >= 0) x += B[o2 + col];
+    return x;
+}      // rows whose right-hand sides are fetched ahead of the dependent substitution chain
 __global__ void __launch_bounds__(64)
-k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, double *__restrict__ A,
+k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA, const int64_t *__restrict__ boffB,
+        double *__restrict__ A, const int64_t *__restrict__ aoffA, const int64_t *__restrict__ aoffB,
         const int *__restrict__ cls, const int *__restrict__ cmeta, const double *__restrict__ gl,
         const double *__restrict__ gr, const double *__restrict__ Lband, const double *__restrict__ Ldinv,
-        const double *__restrict__ Larrow, int nb, int Zb, int K2) {
-    const int vz = blockIdx.y;                      // (v, zm)
-    const int v = vz / Zb;
+        const double *__restrict__ Larrow, int nb, int Zb, int K2, int vz0) {
+    // Row m of the right-hand side is Bsrc[boffA[m] + col] (+ Bsrc[boffB[m] + col] where a second tile overlaps, boffB >= 0);
+    // row m of the solution goes to A[aoffA[m] + col] and, in the final sweep, also to A[aoffB[m] + col] if aoffB >= 0.
+    const int vz = blockIdx.y;                      // local (v, zm) group; vz0 + vz is the patch-level group
+    const int v = (vz0 + vz) / Zb;
     const int k0 = (blockIdx.x == gridDim.x - 1);   // the last block in x handles the k = 0 column
     int blk;
     if (k0) {
@@ -230,7 +240,6 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, dou
         blk = blockIdx.x * 64 + threadIdx.x;
         if (blk >= K2 || (K2 > 1 && blk < 2)) return;            // block 0 -> k0 launch, block 1 is padding (stays zero)
     }
-    const int64_t C = (int64_t)gridDim.y * K2;
     const int64_t col = (int64_t)vz * K2 + blk;
     const int c = cls[v * 2 + (k0 ? 0 : 1)];
     const int n = cmeta[c * 4 + 0], per = cmeta[c * 4 + 1], rl = cmeta[c * 4 + 2], rr = cmeta[c * 4 + 3];
@@ -238,8 +247,14 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, dou
     const double *Ld = Ldinv + (int64_t)c * nb;
     const double *La = Larrow + (int64_t)c * 3 * nb;
     const double *g_l = gl + c * 6, *g_r = gr + c * 6;
-#define BROW(m) Bsrc[rowoff[m] + col]
-#define AROW(m) A[(int64_t)(m) * C + col]
+#define BROW(m) brow(Bsrc, boffA, boffB, (m), col)
+#define AROW(m) A[aoffA[m] + col]
+#define AFIN(m, val)                                    \
+    do {                                                \
+        const double v_ = (val);                        \
+        A[aoffA[m] + col] = v_;                         \
+        if (aoffB[m] >= 0) A[aoffB[m] + col] = v_;      \
+    } while (0)
     if (!per) {
         // forward substitution; the free unknown i lives in row rl + i of A
         double y1 = 0.0, y2 = 0.0, y3 = 0.0;     // y[i-1], y[i-2], y[i-3]
@@ -285,7 +300,7 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, dou
                     if (i + 3 < n) s -= Lb[(int64_t)(i + 3) * 4 + 0] * x3;
                     s *= Ld[i];
                     x3 = x2; x2 = x1; x1 = s;
-                    AROW(rl + i) = s;
+                    AFIN(rl + i, s);
                     if (i == n - 1) xr0 = s;
                     if (i == n - 2) xr1 = s;
                     if (i == 1) xl1 = s;
@@ -293,8 +308,8 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, dou
                 }
             }
         }
-        for (int q = 0; q < rl; q++) AROW(q) = g_l[q * 2] * xl0 + g_l[q * 2 + 1] * xl1;
-        for (int q = 0; q < rr; q++) AROW(nb - 1 - q) = g_r[q * 2] * xr0 + g_r[q * 2 + 1] * xr1;
+        for (int q = 0; q < rl; q++) AFIN(q, g_l[q * 2] * xl0 + g_l[q * 2 + 1] * xl1);
+        for (int q = 0; q < rr; q++) AFIN(nb - 1 - q, g_r[q * 2] * xr0 + g_r[q * 2 + 1] * xr1);
     } else {
         // periodic: unknown i <-> row i + 1; rows 0, nb-2, nb-1 fold onto unknowns n-1, 0, 1
         double y1 = 0.0, y2 = 0.0, y3 = 0.0;
@@ -319,9 +334,9 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, dou
         const double u2 = t2 / La[2 * nb + n - 1];
         const double u1 = (t1 - La[2 * nb + n - 2] * u2) / La[nb + n - 2];
         const double u0 = (t0 - La[nb + n - 3] * u1 - La[2 * nb + n - 3] * u2) / La[n - 3];
-        AROW(n - 2) = u0;
-        AROW(n - 1) = u1;
-        AROW(n) = u2;
+        AFIN(n - 2, u0);
+        AFIN(n - 1, u1);
+        AFIN(n, u2);
         double x1 = 0.0, x2 = 0.0, x3 = 0.0;
         double first0 = 0.0, first1 = 0.0;
         for (int i = n - 4; i >= 0; i--) {
@@ -332,16 +347,32 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ rowoff, dou
             s -= La[i] * u0 + La[nb + i] * u1 + La[2 * nb + i] * u2;
             s *= Ld[i];
             x3 = x2; x2 = x1; x1 = s;
-            AROW(i + 1) = s;
+            AFIN(i + 1, s);
             if (i == 0) first0 = s;
             if (i == 1) first1 = s;
         }
-        AROW(0) = u2;            // a_{-1} = a_{n-1}
-        AROW(nb - 2) = first0;   // a_{n}  = a_0
-        AROW(nb - 1) = first1;   // a_{n+1} = a_1
+        AFIN(0, u2);            // a_{-1} = a_{n-1}
+        AFIN(nb - 2, first0);   // a_{n}  = a_0
+        AFIN(nb - 1, first1);   // a_{n+1} = a_1
     }
 #undef BROW
 #undef AROW
+#undef AFIN
+}
+
+// Transposed (all-to-all) patch solve, tile side: split the tile's [row][col] arrays by destination column range.
+//   pack:   send[soff[d] + j * cw[d] + (col - cs[d])] = B[j][col]
+//   unpack: A[(cell0 + j)][col] = recv[soff[d] + j * cw[d] + (col - cs[d])]        d = owner of col's (v, z-mode) group
+__global__ void k_a2a_pack(const double *__restrict__ B, double *__restrict__ send, const int *__restrict__ owner,
+                           const int64_t *__restrict__ soff, const int64_t *__restrict__ cw, const int64_t *__restrict__ cs,
+                           int K2, int64_t C, int unpack, int64_t brow0) {
+    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (col >= C) return;
+    const int d = owner[col / K2];
+    const int64_t o = soff[d] + (int64_t)j * cw[d] + (col - cs[d]);
+    if (unpack) const_cast<double *>(B)[(brow0 + j) * C + col] = send[o];
+    else send[o] = B[(brow0 + j) * C + col];
 }
 
 __global__ void k_halo_add(double *__restrict__ B, const double *__restrict__ recv, int64_t n) {
@@ -373,6 +404,10 @@ struct PhysArgs {
     double ts;
     double par[SX_NPARAMS];
 };
+
+// A diagnostic variable has expdot == 0 for ever (src/shallowWaterModels.jl:69, 185, 430): explicit_timestep reduces to
+// var_np1 = value, and its (all-zero) tendency history is neither read nor written.
+__device__ __forceinline__ void diag_step(const PhysArgs &a, int v, int64_t p, double u) { a.np1[(int64_t)v * a.N + p] = u; }
 
 // explicit_timestep (src/semiimplicit.jl:672-698); history arrays are rotated by the host instead of copied
 __device__ __forceinline__ double ab_step(const PhysArgs &a, int v, int64_t p, double u, double en) {
@@ -446,7 +481,7 @@ __global__ void k_phys_pointwise(PhysArgs a) {
             ab_step(a, 2, p, vg, e2);
             ab_step(a, 3, p, ub, e3);
             ab_step(a, 4, p, vb, e4);
-            ab_step(a, 5, p, w, 0.0);
+            diag_step(a, 5, p, w);
             for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
         } break;
         case SX_EQ_LINEAR_ACOUSTIC_RZ: {
@@ -540,7 +575,7 @@ __global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgs a, int cpb) {
     ab_step(a, 2, p, vg, e2);
     ab_step(a, 3, p, ub, e3);
     ab_step(a, 4, p, vb, e4);
-    ab_step(a, 5, p, wb, 0.0);
+    diag_step(a, 5, p, wb);
     for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
 }
 
@@ -630,7 +665,7 @@ __global__ void __launch_bounds__(16 * NZ) k_phys_hrbl_mfma(PhysArgs a) {
     ab_step(a, 2, p, vg, e2);
     ab_step(a, 3, p, ub, e3);
     ab_step(a, 4, p, vb, e4);
-    ab_step(a, 5, p, wb, 0.0);
+    diag_step(a, 5, p, wb);
     for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
 }
 
@@ -834,8 +869,35 @@ void launch_solve(sx_handle *h) {
     const int id = timer_id(h, "k_solve");
     timer_begin(h, id);
     dim3 g((h->K2 > 1 ? (h->K2 + 63) / 64 : 0) + 1, h->V * h->Zb);
-    hipLaunchKernelGGL(k_solve, g, dim3(64), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_A, h->d_cls, h->d_cmeta, h->d_gl,
-                       h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2);
+    hipLaunchKernelGGL(k_solve, g, dim3(64), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff, h->d_neg1, h->d_cls,
+                       h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2, 0);
+    HIPCHK(hipGetLastError());
+    timer_end(h);
+}
+
+// transposed solve: my column groups [g0, g1), right-hand sides from the all-to-all receive buffer, solution rows into
+// the all-to-all send buffer (both [tile][row][my columns]; a row shared by two tiles is summed on input, duplicated on output)
+void launch_solve_a2a(sx_handle *h, const double *recv, double *send) {
+    const int id = timer_id(h, "k_solve");
+    timer_begin(h, id);
+    const int ng = h->a2a_g1 - h->a2a_g0;
+    if (ng > 0) {
+        dim3 g((h->K2 > 1 ? (h->K2 + 63) / 64 : 0) + 1, ng);
+        hipLaunchKernelGGL(k_solve, g, dim3(64), 0, h->stream, recv, h->d_a2a_offA, h->d_a2a_offB, send, h->d_a2a_offA, h->d_a2a_offB,
+                           h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2,
+                           h->a2a_g0);
+        HIPCHK(hipGetLastError());
+    }
+    timer_end(h);
+}
+
+void launch_a2a_pack(sx_handle *h, double *buf, int unpack) {
+    const int id = timer_id(h, unpack ? "k_a2a_unpack" : "k_a2a_pack");
+    timer_begin(h, id);
+    dim3 g((unsigned)((h->C + 255) / 256), h->nbt);
+    const double *arr = unpack ? h->d_A : h->d_Btile;
+    hipLaunchKernelGGL(k_a2a_pack, g, dim3(256), 0, h->stream, arr, buf, h->d_a2a_owner, h->d_a2a_soff, h->d_a2a_cw, h->d_a2a_cs,
+                       h->K2, h->C, unpack, (int64_t)(unpack ? h->cell0 : 0));
     HIPCHK(hipGetLastError());
     timer_end(h);
 }

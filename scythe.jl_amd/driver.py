@@ -109,10 +109,89 @@ class DistExchange:
             dist.all_gather_into_tensor(self.buf.view(-1), self.buf[r].reshape(-1), group=self.group)
 
 
+class A2ALayout:
+    """Buffer geometry of the transposed solve for tile `me` (see include/scythe_hip.h, sx_a2a_*)."""
+
+    def __init__(self, layout: PatchLayout, col_starts, me):
+        self.n = layout.num_tiles
+        self.rows = [layout.rows(t) for t in range(self.n)]
+        self.cw = [int(col_starts[d + 1] - col_starts[d]) for d in range(self.n)]
+        self.me = me
+        # tile side: [dest d][row][cw[d]];  owner side: [tile t][row][cw[me]]
+        self.tile_split = [self.rows[me] * self.cw[d] for d in range(self.n)]
+        self.owner_split = [self.rows[t] * self.cw[me] for t in range(self.n)]
+        self.tile_elems = sum(self.tile_split)
+        self.owner_elems = sum(self.owner_split)
+
+
+class LocalA2AExchange:
+    """Transposed solve with all tiles in this process (single-GPU test of the pack / solve / unpack kernels)."""
+
+    def __init__(self, layout: PatchLayout, tiles, device):
+        torch = _torch()
+        self.tiles = tiles
+        self.lay = []
+        for t, g in enumerate(tiles):
+            cs = g.a2a_configure(layout.cell0, layout.ncells, t)
+            self.lay.append(A2ALayout(layout, cs, t))
+        z = lambda n: torch.zeros(max(n, 1), dtype=torch.float64, device=device)
+        self.tile_buf = [z(l.tile_elems) for l in self.lay]      # pack output / unpack input
+        self.own_in = [z(l.owner_elems) for l in self.lay]
+        self.own_out = [z(l.owner_elems) for l in self.lay]
+
+    def _all_to_all(self, src, src_splits, dst, dst_splits):
+        n = len(src)
+        for s in range(n):
+            so = 0
+            for d in range(n):
+                cnt = src_splits[s][d]
+                do = sum(dst_splits[d][:s])
+                dst[d][do:do + cnt] = src[s][so:so + cnt]
+                so += cnt
+
+    def exchange_and_solve(self):
+        for g, b in zip(self.tiles, self.tile_buf):
+            g.a2a_pack_b(b.data_ptr())
+        self._all_to_all(self.tile_buf, [l.tile_split for l in self.lay], self.own_in, [l.owner_split for l in self.lay])
+        for g, i, o in zip(self.tiles, self.own_in, self.own_out):
+            g.a2a_solve(i.data_ptr(), o.data_ptr())
+        self._all_to_all(self.own_out, [l.owner_split for l in self.lay], self.tile_buf, [l.tile_split for l in self.lay])
+        for g, b in zip(self.tiles, self.tile_buf):
+            g.a2a_unpack_a(b.data_ptr())
+
+
+class DistA2AExchange:
+    """Transposed solve, one tile per rank: two all_to_all_single calls per step (RCCL over xGMI on the GPU box)."""
+
+    def __init__(self, layout: PatchLayout, tile, device, group=None, col_starts=None):
+        torch = _torch()
+        import torch.distributed as dist
+        self.dist, self.group, self.tile = dist, group, tile
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        assert self.world == layout.num_tiles
+        if tile is not None:
+            col_starts = tile.a2a_configure(layout.cell0, layout.ncells, self.rank)
+        self.lay = A2ALayout(layout, col_starts, self.rank)
+        z = lambda n: torch.zeros(max(n, 1), dtype=torch.float64, device=device)
+        self.tile_buf, self.tile_buf2 = z(self.lay.tile_elems), z(self.lay.tile_elems)
+        self.own_in, self.own_out = z(self.lay.owner_elems), z(self.lay.owner_elems)
+
+    def exchange_and_solve(self, pack=None, solve=None, unpack=None):
+        """pack / solve / unpack default to the tile's device kernels; the CPU tests pass numpy stand-ins."""
+        lay, dist = self.lay, self.dist
+        (pack or (lambda b: self.tile.a2a_pack_b(b.data_ptr())))(self.tile_buf)
+        dist.all_to_all_single(self.own_in, self.tile_buf, lay.owner_split, lay.tile_split, group=self.group)
+        (solve or (lambda i, o: self.tile.a2a_solve(i.data_ptr(), o.data_ptr())))(self.own_in, self.own_out)
+        dist.all_to_all_single(self.tile_buf2, self.own_out, lay.tile_split, lay.owner_split, group=self.group)
+        (unpack or (lambda b: self.tile.a2a_unpack_a(b.data_ptr())))(self.tile_buf2)
+
+
 class ModelRun:
     """initialize_model + run_model state for one process (src/semiimplicit.jl:126-256)."""
 
-    def __init__(self, model: ModelParameters, num_tiles=1, rank=None, device=None, use_dist=False):
+    def __init__(self, model: ModelParameters, num_tiles=1, rank=None, device=None, use_dist=False, exchange="a2a"):
+        """exchange: "a2a" = transposed solve over all-to-all (scales), "gather" = the reference's protocol
+        (halo chain + gather of owned rows + redundant patch solve on every tile)."""
         self.model = model
         patch = model.grid_params
         self.patch = patch
@@ -128,11 +207,16 @@ class ModelRun:
                           for t in range(num_tiles)]
             self.tile_ids = list(range(num_tiles))
         self.exchange = None
+        self.exchange_kind = exchange if num_tiles > 1 else "none"
         if num_tiles > 1:
-            if use_dist:
-                self.exchange = DistExchange(self.layout, self.tiles[0], device)
+            if exchange == "a2a":
+                self.exchange = (DistA2AExchange(self.layout, self.tiles[0], device) if use_dist
+                                 else LocalA2AExchange(self.layout, self.tiles, device))
+            elif exchange == "gather":
+                self.exchange = (DistExchange(self.layout, self.tiles[0], device) if use_dist
+                                 else LocalExchange(self.layout, self.tiles, device))
             else:
-                self.exchange = LocalExchange(self.layout, self.tiles, device)
+                raise ValueError("exchange must be 'a2a' or 'gather'")
         self.t = 0
 
     def tile_points(self, t):
@@ -146,6 +230,9 @@ class ModelRun:
         self._exchange_and_solve()
 
     def _exchange_and_solve(self):
+        if self.exchange_kind == "a2a":
+            self.exchange.exchange_and_solve()
+            return
         if self.exchange is not None:
             self.exchange.exchange()
         for g in self.tiles:

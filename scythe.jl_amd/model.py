@@ -335,6 +335,25 @@ class Grid:
     def halo_add(self, dev_ptr):
         L.check(self._lib.sx_halo_add(self._h, C.c_void_p(dev_ptr)))
 
+    # -- transposed (all-to-all) patch solve
+    def a2a_configure(self, cell0, ncells, my_tile):
+        n = len(cell0)
+        c0 = (C.c_int32 * n)(*cell0)
+        nc = (C.c_int32 * n)(*ncells)
+        L.check(self._lib.sx_a2a_configure(self._h, n, my_tile, c0, nc))
+        cs = np.zeros(n + 1, dtype=np.int64)
+        L.check(self._lib.sx_a2a_col_starts(self._h, cs.ctypes.data_as(L.P_I64)))
+        return cs
+
+    def a2a_pack_b(self, dev_send):
+        L.check(self._lib.sx_a2a_pack_b(self._h, C.c_void_p(dev_send)))
+
+    def a2a_solve(self, dev_recv, dev_send):
+        L.check(self._lib.sx_a2a_solve(self._h, C.c_void_p(dev_recv), C.c_void_p(dev_send)))
+
+    def a2a_unpack_a(self, dev_recv):
+        L.check(self._lib.sx_a2a_unpack_a(self._h, C.c_void_p(dev_recv)))
+
     # -- timers
     def enable_timers(self, on=True):
         L.check(self._lib.sx_enable_timers(self._h, int(on)))

@@ -153,10 +153,10 @@ def hip_params(case):
 class HipModel:
     """The product path: tiles are libscythe_hip handles, exchange on device buffers."""
 
-    def __init__(self, case, num_tiles=1, device="cuda"):
+    def __init__(self, case, num_tiles=1, device="cuda", exchange="a2a"):
         import scythe_jl_amd as S
         self.gp, self.mp = hip_params(case)
-        self.run = S.ModelRun(self.mp, num_tiles=num_tiles, device=device)
+        self.run = S.ModelRun(self.mp, num_tiles=num_tiles, device=device, exchange=exchange)
         vals = []
         for g in self.run.tiles:
             pts = S.getGridpoints(g)
@@ -171,6 +171,8 @@ class HipModel:
 
     @property
     def A(self):
+        if self.run.exchange_kind == "a2a":
+            return None          # no tile holds the whole patch in the transposed solve
         return self.run.tiles[0].patchSpectral
 
 

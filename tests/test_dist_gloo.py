@@ -91,3 +91,82 @@ def test_halo_and_gather_reproduce_shared_sum(case_name, world):
     res = dict(q.get(timeout=5) for _ in range(world))
     assert sorted(res) == list(range(world))
     assert max(res.values()) < 1e-14
+
+
+# ----------------------------------------------------------------------------- transposed (all-to-all) solve
+def _a2a_worker(rank, world, port, case_name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        case = getattr(cases, case_name)(num_cells=10)
+        gp, _ = cases.hip_params(case)
+        g = cases.oracle_grid(case)
+        K2 = g.K2
+        G = g.V * g.b_zDim
+        n_cols = G * K2
+        lay = S.PatchLayout(gp, world, n_cols=n_cols)
+        col_starts = np.array([(G * d // world) * K2 for d in range(world + 1)], dtype=np.int64)   # rule of sx_a2a_configure
+        pts = g.gridpoints().reshape(-1, 1 + g.has_l + g.has_z)
+        vals = case["ic"](pts)
+        shared = np.zeros((g.S_patch(), g.V), order="F")
+        mine, p0 = None, 0
+        for t in range(world):
+            tl = OC.TileOracle(g, lay.cell0[t], lay.ncells[t])
+            b = tl.forward(vals[p0:p0 + tl.N])
+            p0 += tl.N
+            tl.add_to_shared(b, shared)
+            if t == rank:
+                mine = _to_rows(g, b, tl.og.K2t, lay.rows(t))
+        expected = _patch_rows(g, shared)                       # the reference's shared-array sum, [b_rDim][cols]
+        ex = S.DistA2AExchange(lay, None, "cpu", col_starts=col_starts)
+        al = ex.lay
+        c0, c1 = col_starts[rank], col_starts[rank + 1]
+
+        def pack(buf):
+            buf[:] = torch.from_numpy(np.concatenate([mine[:, col_starts[d]:col_starts[d + 1]].ravel() for d in range(world)]))
+
+        def solve(inp, out):
+            # stand-in for the banded solve: identity on the summed rows (checks the overlap-sum and duplication layout)
+            full = np.zeros((g.b_rDim, c1 - c0))
+            o = 0
+            for t in range(world):
+                n = al.rows[t]
+                full[lay.cell0[t]:lay.cell0[t] + n] += inp[o:o + n * (c1 - c0)].numpy().reshape(n, c1 - c0)
+                o += n * (c1 - c0)
+            out[:] = torch.from_numpy(np.concatenate([full[lay.cell0[t]:lay.cell0[t] + al.rows[t]].ravel() for t in range(world)]))
+
+        got = {}
+
+        def unpack(buf):
+            rows = np.zeros((al.rows[rank], n_cols))
+            o = 0
+            for d in range(world):
+                w = col_starts[d + 1] - col_starts[d]
+                rows[:, col_starts[d]:col_starts[d + 1]] = buf[o:o + al.rows[rank] * w].numpy().reshape(al.rows[rank], w)
+                o += al.rows[rank] * w
+            got["rows"] = rows
+
+        ex.exchange_and_solve(pack=pack, solve=solve, unpack=unpack)
+        want = expected[lay.cell0[rank]:lay.cell0[rank] + al.rows[rank]]
+        q.put((rank, float(np.abs(got["rows"] - want).max() / np.abs(expected).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case_name,world", [("rl_slab", 2), ("rlz_hrbl", 3)])
+def test_all_to_all_transpose_layout(case_name, world):
+    """Uneven all_to_all_single splits: every tile gets back exactly the patch rows it evaluates, with the rows two
+    tiles share summed once (the reference's halo add) and delivered to both."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_a2a_worker, args=(r, world, port, case_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert sorted(res) == list(range(world))
+    assert max(res.values()) < 1e-14

@@ -8,11 +8,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10     # north_star: fields within 1e-10 relative of the CPU reference
 
 
-def _run(case, nsteps, num_tiles=1, oracle_tiles=None):
-    hip = cases.HipModel(case, num_tiles=num_tiles)
+def _run(case, nsteps, num_tiles=1, oracle_tiles=None, exchange="a2a"):
+    hip = cases.HipModel(case, num_tiles=num_tiles, exchange=exchange)
     orc = cases.OracleModel(case, tiles=oracle_tiles)
-    e0 = cases.rel_err(hip.A, orc.A)
-    assert e0 < TOL, "initial A coefficients differ: %g" % e0
+    if hip.A is not None:
+        e0 = cases.rel_err(hip.A, orc.A)
+        assert e0 < TOL, "initial A coefficients differ: %g" % e0
     for _ in range(nsteps):
         hip.step()
         orc.step()
@@ -76,7 +77,9 @@ def test_rlz_advection():
 @pytest.mark.parametrize("maker,kw,ntiles", [(cases.kat_r, {}, 2), (cases.kat_r, {}, 3), (cases.rl_slab, {"num_cells": 9}, 2),
                                              (cases.rl_slab, {"num_cells": 10}, 3), (cases.rlz_hrbl, {"num_cells": 7}, 2),
                                              (cases.rz_semiimplicit, {"num_cells": 9}, 3)])
-def test_tiles_on_one_gpu_match_single_patch_oracle(maker, kw, ntiles):
-    """Several tile handles on one GPU, halo + gather on device buffers, against the one-patch oracle."""
+@pytest.mark.parametrize("exchange", ["gather", "a2a"])
+def test_tiles_on_one_gpu_match_single_patch_oracle(maker, kw, ntiles, exchange):
+    """Several tile handles on one GPU against the one-patch oracle: "gather" = halo + gather of owned rows + redundant
+    solve (the reference's protocol), "a2a" = transposed solve (pack / all-to-all / solve / all-to-all / unpack)."""
     case = maker(**kw)
-    assert _run(case, 4, num_tiles=ntiles) < TOL
+    assert _run(case, 4, num_tiles=ntiles, exchange=exchange) < TOL
