@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--workload", default="rlz_513x256x64", choices=sorted(WORKLOADS))
     ap.add_argument("--exchange", default="a2a", choices=["a2a", "gather"],
                     help="multi-GPU patch solve: transposed all-to-all (default) or the reference's halo + gather protocol")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --one-device rehearses the multi-rank path on a single GPU (not a performance mode)")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=18)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -112,12 +115,17 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     kw, L = grid_kwargs(args.workload)
     gp = S.GridParameters(ring_uniform_L=L, **kw)
@@ -151,7 +159,7 @@ def main():
     nan = tile.check_nan()
 
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -85,6 +85,7 @@ class DistExchange:
         if tile is not None:
             tile.bind_tile_b(self.buf[self.rank].data_ptr())
             tile.bind_patch_b(self.buf.data_ptr(), layout.row_offsets(C))
+        self.stage_host = (dist.get_backend(group) == "gloo" and self.buf.is_cuda)   # one-GPU rehearsal only
 
     def my_rows(self):
         return self.buf[self.rank]
@@ -95,18 +96,29 @@ class DistExchange:
         if W > 1:
             ops = []
             n = self.layout.ncells[r]
+            send = self.buf[r, n:n + 3]
+            recv = self.halo
+            if self.stage_host:
+                send, recv = send.cpu(), self.halo.cpu()
             if r < W - 1:
-                ops.append(dist.P2POp(dist.isend, self.buf[r, n:n + 3], r + 1, self.group))
+                ops.append(dist.P2POp(dist.isend, send, r + 1, self.group))
             if r > 0:
-                ops.append(dist.P2POp(dist.irecv, self.halo, r - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, recv, r - 1, self.group))
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
             if r > 0:
+                if self.stage_host:
+                    self.halo.copy_(recv)
                 if halo_add is not None:
                     halo_add(self.halo)
                 else:
                     self.tile.halo_add(self.halo.data_ptr())
-            dist.all_gather_into_tensor(self.buf.view(-1), self.buf[r].reshape(-1), group=self.group)
+            if self.stage_host:
+                full = self.buf.cpu()
+                dist.all_gather_into_tensor(full.view(-1), full[r].reshape(-1).clone(), group=self.group)
+                self.buf.copy_(full)
+            else:
+                dist.all_gather_into_tensor(self.buf.view(-1), self.buf[r].reshape(-1), group=self.group)
 
 
 class A2ALayout:
@@ -175,14 +187,25 @@ class DistA2AExchange:
         z = lambda n: torch.zeros(max(n, 1), dtype=torch.float64, device=device)
         self.tile_buf, self.tile_buf2 = z(self.lay.tile_elems), z(self.lay.tile_elems)
         self.own_in, self.own_out = z(self.lay.owner_elems), z(self.lay.owner_elems)
+        # gloo cannot move device tensors through all_to_all: stage through the host (rehearsal on one GPU only;
+        # the production backend is "nccl" = RCCL, which takes the device buffers directly)
+        self.stage_host = (dist.get_backend(group) == "gloo" and self.tile_buf.is_cuda)
+
+    def _a2a(self, out, inp, out_split, in_split):
+        if self.stage_host:
+            o = out.cpu()
+            self.dist.all_to_all_single(o, inp.cpu(), out_split, in_split, group=self.group)
+            out.copy_(o)
+        else:
+            self.dist.all_to_all_single(out, inp, out_split, in_split, group=self.group)
 
     def exchange_and_solve(self, pack=None, solve=None, unpack=None):
         """pack / solve / unpack default to the tile's device kernels; the CPU tests pass numpy stand-ins."""
-        lay, dist = self.lay, self.dist
+        lay = self.lay
         (pack or (lambda b: self.tile.a2a_pack_b(b.data_ptr())))(self.tile_buf)
-        dist.all_to_all_single(self.own_in, self.tile_buf, lay.owner_split, lay.tile_split, group=self.group)
+        self._a2a(self.own_in, self.tile_buf, lay.owner_split, lay.tile_split)
         (solve or (lambda i, o: self.tile.a2a_solve(i.data_ptr(), o.data_ptr())))(self.own_in, self.own_out)
-        dist.all_to_all_single(self.tile_buf2, self.own_out, lay.tile_split, lay.owner_split, group=self.group)
+        self._a2a(self.tile_buf2, self.own_out, lay.tile_split, lay.owner_split)
         (unpack or (lambda b: self.tile.a2a_unpack_a(b.data_ptr())))(self.tile_buf2)
 
 
