@@ -37,6 +37,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// workgroup barrier that orders LDS traffic only: outstanding global stores (the previous slot's copy-out) and loads
+// stay in flight across it (a plain __syncthreads() would also drain vmcnt)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int LOGL>
 struct Twiddles {
     static constexpr int L = 1 << LOGL, T = L / 4, NP4 = LOGL / 2;
@@ -130,7 +138,9 @@ k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const
     const int za = 2 * f, zb = 2 * f + 1;
     const bool active = (f < FNP) && (za < zc);
     const bool hasb = zb < zc;
-    double2 *X = smf + f * (L + SKEW);
+    // two sets of FNP transform regions: slot i works in set i & 1, so the copy-out of slot i (global stores, never
+    // waited for) overlaps the staging and transform of slot i + 1; one LDS-only workgroup barrier per slot
+    int par = 0;
     Twiddles<LOGL> tw;
     tw.template init<+1>(twg, t);
     const int j0 = ring / MUBAR;
@@ -178,6 +188,9 @@ k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const
         for (int ld = 0; ld < 3; ld++) {
             if (!(ld == 0 ? n0 : ld == 1 ? n1 : n2)) continue;
             const int slot = ld == 0 ? sl0 : ld == 1 ? sl1 : sl2;
+            double2 *set = smf + (COPYOUT ? par * FNP * (L + SKEW) : 0);
+            double2 *X = set + f * (L + SKEW);
+            par ^= 1;
             if (active) {
                 double2 c1 = a1, e1 = b1, c2 = a2, e2 = b2;
                 if (ld == 1) {                                     // multiply by ik
@@ -199,18 +212,17 @@ k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const
             if (COPYOUT) {
                 // last pass goes back to LDS, then the whole workgroup writes full 128-byte lines
                 fft_inplace<LOGL, +1, true>(X, tw, t, active);
-                __syncthreads();
+                lds_barrier();       // also orders the previous slot's copy-out reads (other set) before that set is restaged
                 double *out = phys + ((int64_t)slot * V + v) * N + p0 * nz + z0;
                 {
                     // thread -> (level zz, ring point l0 + 32 i): consecutive lanes cover the 16 levels of one point
                     const int zz = threadIdx.x & (FZC - 1);
-                    const double *src = reinterpret_cast<const double *>(smf + (zz >> 1) * (L + SKEW)) + (zz & 1);
+                    const double *src = reinterpret_cast<const double *>(set + (zz >> 1) * (L + SKEW)) + (zz & 1);
                     if (zz < zc) {
 #pragma unroll 4
                         for (int l = threadIdx.x >> 4; l < L; l += (int)(blockDim.x >> 4)) out[(int64_t)l * nz + zz] = src[2 * l];
                     }
                 }
-                __syncthreads();
             } else {
                 double *out = phys + ((int64_t)slot * V + v) * N + p0 * nz + z0 + za;
                 fft_inplace<LOGL, +1>(X, tw, t, active, [&](int l, double2 y) {
@@ -285,7 +297,7 @@ bool fft_path_ok(const sx_handle *h) {
     return h->has_l && L >= 16 && L <= 256 && (L & (L - 1)) == 0;   // one transform = L/4 <= 64 lanes of one wave
 }
 
-static size_t fft_lds(int L) { return sizeof(double2) * (size_t)FNP * (L + SKEW); }
+static size_t fft_lds(int L, int sets = 1) { return sizeof(double2) * (size_t)sets * FNP * (L + SKEW); }
 static int fft_threads(int L) { return std::max(64, FNP * (L / 4)); }
 
 template <int LOGL>
@@ -293,7 +305,7 @@ static void launch_inv(sx_handle *h, const int *d_mask, dim3 g, const double *az
     const int L = 1 << LOGL;
     static const int copyout = getenv("SX_FFT_COPYOUT") ? atoi(getenv("SX_FFT_COPYOUT")) : 1;
     if (copyout)
-        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, az, h->d_phys, h->d_phi,
+        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az, h->d_phys, h->d_phi,
                            h->d_kmax, h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, h->nrings,
                            h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);
     else
