@@ -171,6 +171,12 @@ def main():
         bytes_per_launch = tile.kernel_bytes(name)
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         nc, _, nz = WORKLOADS[args.workload]
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE,
+        # collected and corrected as profiles/summarize_pmc.py documents); null for other workloads / tilings
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_%s.json" % args.workload)
+        if world == 1 and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(name, {}).get("hbm_bytes")
         out = {
             "metric": "model steps/sec, RLZ 512x256x64 shallow-water",
             "value": args.steps / elapsed,
@@ -189,7 +195,7 @@ def main():
                                    % (3 * nc, L, nz, L // 2 - 1, int(tile.dims.b_zDim)),
                        "num_cells": nc, "tiles": world, "exchange": run.exchange_kind, "ts": TS, "nan": bool(nan)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
         }
