@@ -206,20 +206,19 @@ class ModelOracle:
         if g.has_z:
             hv = "h" if "h" in g.vars else g.names[0]
             ch = g.cheb(hv)
-            self.Mint = np.ascontiguousarray(ch.Mint @ ch.CBm)
-            self.Mdz = np.ascontiguousarray(ch.M[1] @ ch.CBm)
+            self.Mint = np.ascontiguousarray(ch.Vint)
+            self.Mdz = np.ascontiguousarray(ch.Vdz)
         if self.semi:
             chx = g.cheb("xi")
-            self.Mdz = np.ascontiguousarray(chx.M[1] @ chx.CBm)
-            self.Mrec = np.ascontiguousarray(chx.M[0] @ chx.CBm)
+            self.Mdz = np.ascontiguousarray(chx.Vdz)
+            self.Mrec = np.ascontiguousarray(chx.Vrec)
 
     def _semi_mats(self, tau):
         if tau not in self._mats:
             g = self.g
             chw = g.cheb("w")
-            H = O.helmholtz_matrix(chw, self.par[PAR_ORDER.index("Pxi_bar")], tau)
-            Hinv = np.linalg.inv(H)
-            self._mats[tau] = (np.ascontiguousarray(chw.T @ Hinv), np.ascontiguousarray(chw.T @ chw.Dc @ Hinv))
+            W, X = O.semi_matrices(chw, self.par[PAR_ORDER.index("Pxi_bar")], tau)
+            self._mats[tau] = (np.ascontiguousarray(W), np.ascontiguousarray(X))
         return self._mats[tau]
 
     def set_initial(self, values_patch):

@@ -151,8 +151,16 @@ class Ring:
 
 
 # ----------------------------------------------------------------------------- Chebyshev column
+XP = np.longdouble            # x87 80-bit extended precision on this platform
+PI_X = 4 * np.arctan(XP(1))
+
+
 class Cheb:
-    """Chebyshev-Gauss-Lobatto column, index 0 = bottom (z = zmin, x = +1)."""
+    """Chebyshev-Gauss-Lobatto column, index 0 = bottom (z = zmin, x = +1).
+
+    The operators are assembled in extended precision and rounded to double once: the second-derivative collocation
+    matrix has entries O(N^4 / Lz^2), so factors rounded to double before multiplication would put cond * eps
+    (1e-9 at N = 128) of avoidable noise into every product."""
 
     def __init__(self, zmin, zmax, N, bdim=None, bcb="R0", bct="R0"):
         self.zmin, self.zmax, self.N = float(zmin), float(zmax), int(N)
@@ -161,71 +169,81 @@ class Cheb:
         n = np.arange(N)
         self.x = np.cos(n * np.pi / (N - 1))
         self.z = self.x * (-0.5 * (self.zmax - self.zmin)) + 0.5 * (self.zmin + self.zmax)
-        w = np.full(N, 2.0)
+        w = np.full(N, 2.0, dtype=XP)
         w[0] = w[-1] = 1.0
-        self.T = w[None, :] * np.cos(np.outer(n, n) * np.pi / (N - 1))   # dct_matrix: a -> values
-        self.CBm = (self.T / (2.0 * (N - 1)))[: self.bdim, :]            # values -> b (truncated)
-        Lz = self.zmax - self.zmin
+        nk = np.outer(n, n).astype(XP)
+        Tx = w[None, :] * np.cos(nk * PI_X / XP(N - 1))          # dct_matrix: a -> values
+        CBx = (Tx / XP(2 * (N - 1)))[: self.bdim, :]             # values -> b (truncated)
+        Lz = XP(self.zmax) - XP(self.zmin)
         # coefficient-space derivative (a -> ax), DCT-I normalisation u = a0 + 2 sum a_k T_k + a_{N-1} T_{N-1}
-        Dc = np.zeros((N, N))
+        Dc = np.zeros((N, N), dtype=XP)
         for j in range(N):
-            a = np.zeros(N)
+            a = np.zeros(N, dtype=XP)
             a[j] = 1.0
-            ax = np.zeros(N + 2)
+            ax = np.zeros(N + 2, dtype=XP)
             for k in range(N - 1, 0, -1):
-                ck = a[k] if k == N - 1 else 2.0 * a[k]
+                ck = a[k] if k == N - 1 else 2 * a[k]
                 ax[k - 1] = ax[k + 1] + k * ck
             Dc[:, j] = ax[:N]
-        self.Dc = Dc * (-2.0 / Lz)
+        Dcx = Dc * (XP(-2) / Lz)
         # coefficient-space indefinite integral (zero at the bottom)
-        Ic = np.zeros((N, N))
+        Ic = np.zeros((N, N), dtype=XP)
         for j in range(N):
-            a = np.zeros(N)
+            a = np.zeros(N, dtype=XP)
             a[j] = 1.0
-            ai = np.zeros(N)
+            ai = np.zeros(N, dtype=XP)
             for k in range(1, N - 1):
-                up = a[k + 1] if k + 1 < N - 1 else 0.5 * a[k + 1]
-                ai[k] = (a[k - 1] - up) / (2.0 * k)
-            ai[N - 1] = a[N - 2] / (N - 1)
-            ai *= (-0.5 * Lz)
-            ai[0] = -(2.0 * ai[1:N - 1].sum() + ai[N - 1])
+                up = a[k + 1] if k + 1 < N - 1 else a[k + 1] / 2
+                ai[k] = (a[k - 1] - up) / XP(2 * k)
+            ai[N - 1] = a[N - 2] / XP(N - 1)
+            ai *= (XP(-0.5) * Lz)
+            ai[0] = -(2 * ai[1:N - 1].sum() + ai[N - 1])
             Ic[:, j] = ai
-        self.Ic = Ic
+        TDx = Tx @ Dcx
+        TDDx = TDx @ Dcx
         # BC projection in coefficient space (orthogonal projection onto the constraint null space)
         rows = []
         for bc, row in ((bcb, 0), (bct, N - 1)):
             if bc == "R0":
                 continue
             if bc == "R1T0":
-                rows.append(self.T[row, :])
+                rows.append(Tx[row, :])
             elif bc == "R1T1":
-                rows.append((self.T @ self.Dc)[row, :])
+                rows.append(TDx[row, :])
             elif bc == "R1T2":
-                rows.append((self.T @ self.Dc @ self.Dc)[row, :])
+                rows.append(TDDx[row, :])
             else:
                 raise ValueError("unsupported vertical BC " + bc)
-        pad = np.zeros((N, self.bdim))
-        pad[: self.bdim, : self.bdim] = np.eye(self.bdim)
+        pad = np.zeros((N, self.bdim), dtype=XP)
+        pad[: self.bdim, : self.bdim] = np.eye(self.bdim, dtype=XP)
+        proj = np.eye(N, dtype=XP)
         if rows:
-            C = np.array(rows)
-            proj = np.eye(N) - C.T @ np.linalg.solve(C @ C.T, C)
-        else:
-            proj = np.eye(N)
-        self.CAm = proj @ pad                       # b -> a
-        self.M = [self.T @ self.CAm,                # b -> values
-                  self.T @ self.Dc @ self.CAm,      # b -> d/dz
-                  self.T @ self.Dc @ self.Dc @ self.CAm]
-        self.Mint = self.T @ self.Ic @ self.CAm     # b -> integral from the bottom
+            Cm = np.array(rows, dtype=XP)
+            G = Cm @ Cm.T
+            if len(rows) == 1:
+                Gi = 1 / G
+            else:
+                det = G[0, 0] * G[1, 1] - G[0, 1] * G[1, 0]
+                Gi = np.array([[G[1, 1], -G[0, 1]], [-G[1, 0], G[0, 0]]], dtype=XP) / det
+            proj = proj - Cm.T @ Gi @ Cm
+        CAx = proj @ pad                                # b -> a
+        f64 = lambda m: np.asarray(m, dtype=np.float64)
+        self._x = dict(T=Tx, Dc=Dcx, TD=TDx, TDD=TDDx)       # extended-precision factors (Helmholtz assembly)
+        self.T, self.Dc, self.CBm, self.CAm, self.Ic = f64(Tx), f64(Dcx), f64(CBx), f64(CAx), f64(Ic)
+        self.M = [f64(Tx @ CAx), f64(TDx @ CAx), f64(TDDx @ CAx)]       # b -> values, d/dz, d2/dz2
+        self.Mint = f64(Tx @ Ic @ CAx)                                     # b -> integral from the bottom
+        # full column operators values -> values (CB, CA, then CI / CIx / CIInt), products taken before rounding
+        self.Vrec, self.Vdz, self.Vint = f64(Tx @ CAx @ CBx), f64(TDx @ CAx @ CBx), f64(Tx @ Ic @ CAx @ CBx)
 
     # dense collocation matrices used by calc_Helmholtz_semiimplicit_matrix (src/semiimplicit.jl:772-775)
     def dct_matrix(self):
         return self.T
 
     def dct_1st_derivative(self):
-        return self.T @ self.Dc
+        return np.asarray(self._x["TD"], dtype=np.float64)
 
     def dct_2nd_derivative(self):
-        return self.T @ self.Dc @ self.Dc
+        return np.asarray(self._x["TDD"], dtype=np.float64)
 
 
 def default_bzdim(zdim):
@@ -450,12 +468,37 @@ def explicit_timestep(t, ts, u, e_n, e_nm1, e_nm2):
     return u + ((ts / 12.0) * ((23.0 * e_n) - (16.0 * e_nm1) + (5.0 * e_nm2))), e_n.copy(), e_nm1.copy()
 
 
-def helmholtz_matrix(ch, pxi_bar, tau):
+def helmholtz_matrix(ch, pxi_bar, tau, extended=False):
     """calc_Helmholtz_semiimplicit_matrix (src/semiimplicit.jl:768-781)."""
-    c = tau * tau * pxi_bar
-    dct, dct2 = ch.dct_matrix(), ch.dct_2nd_derivative()
+    c = XP(tau) * XP(tau) * XP(pxi_bar)
+    dct, dct2 = ch._x["T"], ch._x["TDD"]
     h = c * dct2 - dct
-    return np.vstack([c * dct[0:1, :], c * dct[-1:, :], h[1:-1, :]])
+    H = np.vstack([c * dct[0:1, :], c * dct[-1:, :], h[1:-1, :]])
+    return H if extended else np.asarray(H, dtype=np.float64)
+
+
+def inverse_extended(H):
+    """Inverse of a (badly conditioned, cond ~ N^4) Helmholtz matrix by Gauss-Jordan elimination with partial pivoting
+    in extended precision (numpy longdouble = x87 80-bit here). The reference solves with a double-precision LU
+    (src/semiimplicit.jl:586-589); at zDim = 128 that alone carries ~1e-8 relative rounding error, so the oracle
+    evaluates the same operator more accurately instead of adding its own copy of that noise."""
+    n = H.shape[0]
+    A = np.concatenate([H.astype(np.longdouble), np.eye(n, dtype=np.longdouble)], axis=1)
+    for c in range(n):
+        p = c + int(np.argmax(np.abs(A[c:, c])))
+        if p != c:
+            A[[c, p]] = A[[p, c]]
+        A[c] = A[c] / A[c, c]
+        f = A[:, c].copy()
+        f[c] = 0.0
+        A -= np.outer(f, A[c])
+    return A[:, n:]
+
+
+def semi_matrices(ch, pxi_bar, tau):
+    """g -> w values (T H^-1) and g -> dw/dz values (T Dc H^-1) as double matrices."""
+    Hinv = inverse_extended(helmholtz_matrix(ch, pxi_bar, tau, extended=True))
+    return np.asarray(ch._x["T"] @ Hinv, dtype=np.float64), np.asarray(ch._x["TD"] @ Hinv, dtype=np.float64)
 
 
 def tendency(grid, eq, par, phys, pts, col_ops=None):
@@ -502,8 +545,8 @@ def tendency(grid, eq, par, phys, pts, col_ops=None):
     elif eq == "Oneway_ShallowWater_HeightResolvedBL":   # src/shallowWaterModels.jl:346-511
         nz = grid.zDim
         ch = grid.cheb("h")                              # "h" carries no vertical BC (ref :422-425)
-        Mint = ch.Mint @ ch.CBm
-        Mdz = ch.M[1] @ ch.CBm
+        Mint = ch.Vint
+        Mdz = ch.Vdz
         colv = lambda a: a.reshape(-1, nz)
         r, lam, z = colv(pts[:, 0]), colv(pts[:, 1]), colv(pts[:, 2])
         g, Kh, Cd0, Hfree, f, Um, Vm = (par[k] for k in ("g", "Kh", "Cd", "Hfree", "f", "Um", "Vm"))
@@ -636,14 +679,12 @@ class Model:
             star[v] = x.reshape(-1, nz)
         hs["i2"], hs["i1"] = I1.copy(), I_n.copy()
         chx, chw = g.cheb(g.names[xi]), g.cheb(g.names[wi])
-        bxi = star[xi] @ chx.CBm.T
-        xi_star = bxi @ chx.M[0].T
-        xi_star_z = tau * self.pxi * (bxi @ chx.M[1].T)
+        xi_star = star[xi] @ chx.Vrec.T
+        xi_star_z = tau * self.pxi * (star[xi] @ chx.Vdz.T)
         gg = xi_star_z - star[wi]
         rhs = np.zeros_like(gg)
         rhs[:, 2:] = gg[:, 1:nz - 1]
-        H = helmholtz_matrix(chw, self.pxi, tau)
-        wa = np.linalg.solve(H, rhs.T).T
-        out[:, wi] = (wa @ chw.T.T).reshape(-1)
-        out[:, xi] = (xi_star - tau * (wa @ (chw.T @ chw.Dc).T)).reshape(-1)
+        W, X = semi_matrices(chw, self.pxi, tau)
+        out[:, wi] = (rhs @ W.T).reshape(-1)
+        out[:, xi] = (xi_star - tau * (rhs @ X.T)).reshape(-1)
         return out

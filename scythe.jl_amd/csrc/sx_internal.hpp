@@ -21,6 +21,7 @@ struct SplineClass {
 
 struct ChebOps {
     int bcb = 0, bct = 0;
+    double zmin = 0, zmax = 0;
     std::vector<double> z;       // [nz] gridpoints, index 0 = bottom
     std::vector<double> T;       // [nz][nz]  coefficients -> values              (Chebyshev.dct_matrix)
     std::vector<double> Dc;      // [nz][nz]  coefficient-space d/dz

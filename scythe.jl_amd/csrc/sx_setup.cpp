@@ -154,14 +154,48 @@ bool build_spline_class(int nc, double DX, double l_q, int bcl, int bcr, SplineC
 }
 
 // ---------------------------------------------------------------------------------------------- Chebyshev
-static void matmul(const std::vector<double> &A, const std::vector<double> &B, std::vector<double> &Cm, int n, int k, int m) {
-    Cm.assign((size_t)n * m, 0.0);
+// The collocation operators are assembled in extended precision and rounded to double once at the end: the
+// second-derivative matrix has entries O(N^4 / Lz^2), and products of double-rounded factors would carry a relative
+// error of cond * eps into every step (visible as ~1e-9 field differences at zDim = 128).
+typedef long double xreal;
+typedef std::vector<xreal> xmat;
+
+static void matmul(const xmat &A, const xmat &B, xmat &Cm, int n, int k, int m) {
+    Cm.assign((size_t)n * m, 0.0L);
     for (int i = 0; i < n; i++)
         for (int p = 0; p < k; p++) {
-            double a = A[(size_t)i * k + p];
-            if (a == 0.0) continue;
+            xreal a = A[(size_t)i * k + p];
+            if (a == 0.0L) continue;
             for (int j = 0; j < m; j++) Cm[(size_t)i * m + j] += a * B[(size_t)p * m + j];
         }
+}
+
+static std::vector<double> to_double(const xmat &A) { return std::vector<double>(A.begin(), A.end()); }
+
+struct ChebX {       // extended-precision factors shared by build_cheb_ops and build_helmholtz
+    xmat T, Dc, TD, TDD;
+};
+
+static void cheb_factors(double zmin, double zmax, int N, ChebX &x) {
+    const xreal PI = 4.0L * atanl(1.0L);
+    const xreal Lz = (xreal)zmax - (xreal)zmin;
+    x.T.assign((size_t)N * N, 0.0L);
+    for (int n = 0; n < N; n++)
+        for (int k = 0; k < N; k++)
+            x.T[(size_t)n * N + k] = ((k == 0 || k == N - 1) ? 1.0L : 2.0L) * cosl((xreal)((long)n * k) * PI / (xreal)(N - 1));
+    // coefficient-space derivative: ax_{k-1} = ax_{k+1} + k c_k with c_k = 2 a_k (interior), a_{N-1} (last)
+    x.Dc.assign((size_t)N * N, 0.0L);
+    std::vector<xreal> ax(N + 2);
+    for (int j = 0; j < N; j++) {
+        std::fill(ax.begin(), ax.end(), 0.0L);
+        for (int k = N - 1; k >= 1; k--) {
+            xreal ck = (k == j) ? ((k == N - 1) ? 1.0L : 2.0L) : 0.0L;
+            ax[k - 1] = ax[k + 1] + k * ck;
+        }
+        for (int i = 0; i < N; i++) x.Dc[(size_t)i * N + j] = ax[i] * (-2.0L / Lz);
+    }
+    matmul(x.T, x.Dc, x.TD, N, N, N);
+    matmul(x.TD, x.Dc, x.TDD, N, N, N);
 }
 
 bool build_cheb_ops(double zmin, double zmax, int nz, int Zb, int bcb, int bct, ChebOps &o, std::string &err) {
@@ -169,117 +203,105 @@ bool build_cheb_ops(double zmin, double zmax, int nz, int Zb, int bcb, int bct, 
     o.bcb = bcb;
     o.bct = bct;
     const int N = nz;
-    const double Lz = zmax - zmin;
+    const xreal PI = 4.0L * atanl(1.0L);
+    const xreal Lz = (xreal)zmax - (xreal)zmin;
     o.z.resize(N);
-    for (int n = 0; n < N; n++) o.z[n] = std::cos(n * M_PI / (N - 1)) * (-0.5 * Lz) + 0.5 * (zmin + zmax);
-    // T[n][k] = w_k cos(n k pi / (N-1)), w = 1 at the ends, 2 inside (DCT-I / REDFT00 normalisation)
-    o.T.assign((size_t)N * N, 0.0);
-    for (int n = 0; n < N; n++)
-        for (int k = 0; k < N; k++)
-            o.T[(size_t)n * N + k] = ((k == 0 || k == N - 1) ? 1.0 : 2.0) * std::cos((double)n * k * M_PI / (N - 1));
-    o.CB.assign((size_t)Zb * N, 0.0);
+    for (int n = 0; n < N; n++) o.z[n] = std::cos(n * M_PI / (N - 1)) * (-0.5 * (zmax - zmin)) + 0.5 * (zmin + zmax);
+    (void)PI;
+    ChebX x;
+    cheb_factors(zmin, zmax, N, x);
+    xmat CB((size_t)Zb * N);
     for (int k = 0; k < Zb; k++)
-        for (int n = 0; n < N; n++) o.CB[(size_t)k * N + n] = o.T[(size_t)k * N + n] / (2.0 * (N - 1));
-    // coefficient-space derivative: ax_{k-1} = ax_{k+1} + k c_k with c_k = 2 a_k (interior), a_{N-1} (last)
-    o.Dc.assign((size_t)N * N, 0.0);
-    std::vector<double> ax(N + 2);
-    for (int j = 0; j < N; j++) {
-        std::fill(ax.begin(), ax.end(), 0.0);
-        for (int k = N - 1; k >= 1; k--) {
-            double ck = (k == j) ? ((k == N - 1) ? 1.0 : 2.0) : 0.0;
-            ax[k - 1] = ax[k + 1] + k * ck;
-        }
-        for (int i = 0; i < N; i++) o.Dc[(size_t)i * N + j] = ax[i] * (-2.0 / Lz);
-    }
+        for (int n = 0; n < N; n++) CB[(size_t)k * N + n] = x.T[(size_t)k * N + n] / (2.0L * (N - 1));
     // coefficient-space integral, zero at the bottom (x = +1 where every T_k = 1)
-    std::vector<double> Ic((size_t)N * N, 0.0), ai(N);
+    xmat Ic((size_t)N * N, 0.0L);
+    std::vector<xreal> ai(N);
     for (int j = 0; j < N; j++) {
-        std::fill(ai.begin(), ai.end(), 0.0);
-        auto a = [&](int k) { return k == j ? 1.0 : 0.0; };
+        std::fill(ai.begin(), ai.end(), 0.0L);
+        auto a = [&](int k) { return k == j ? 1.0L : 0.0L; };
         for (int k = 1; k < N - 1; k++) {
-            double up = (k + 1 < N - 1) ? a(k + 1) : 0.5 * a(k + 1);
-            ai[k] = (a(k - 1) - up) / (2.0 * k);
+            xreal up = (k + 1 < N - 1) ? a(k + 1) : 0.5L * a(k + 1);
+            ai[k] = (a(k - 1) - up) / (2.0L * k);
         }
-        ai[N - 1] = a(N - 2) / (N - 1);
-        double s = 0.0;
+        ai[N - 1] = a(N - 2) / (xreal)(N - 1);
+        xreal s = 0.0L;
         for (int k = 1; k < N; k++) {
-            ai[k] *= (-0.5 * Lz);
-            s += (k == N - 1 ? 1.0 : 2.0) * ai[k];
+            ai[k] *= (-0.5L * Lz);
+            s += (k == N - 1 ? 1.0L : 2.0L) * ai[k];
         }
         ai[0] = -s;
         for (int i = 0; i < N; i++) Ic[(size_t)i * N + j] = ai[i];
     }
     // BC projection (orthogonal projection onto the null space of the constraint rows)
-    std::vector<double> TD, TDD;
-    matmul(o.T, o.Dc, TD, N, N, N);
-    matmul(TD, o.Dc, TDD, N, N, N);
-    std::vector<std::vector<double>> rows;
+    std::vector<std::vector<xreal>> rows;
     const int bcs[2] = {bcb, bct}, rix[2] = {0, N - 1};
     for (int s = 0; s < 2; s++) {
-        const std::vector<double> *src = nullptr;
+        const xmat *src = nullptr;
         switch (bcs[s]) {
             case SX_BC_R0: continue;
-            case SX_BC_R1T0: src = &o.T; break;
-            case SX_BC_R1T1: src = &TD; break;
-            case SX_BC_R1T2: src = &TDD; break;
+            case SX_BC_R1T0: src = &x.T; break;
+            case SX_BC_R1T1: src = &x.TD; break;
+            case SX_BC_R1T2: src = &x.TDD; break;
             default: err = "unsupported vertical boundary condition"; return false;
         }
         rows.emplace_back(src->begin() + (size_t)rix[s] * N, src->begin() + (size_t)(rix[s] + 1) * N);
     }
-    std::vector<double> proj((size_t)N * N, 0.0);
-    for (int i = 0; i < N; i++) proj[(size_t)i * N + i] = 1.0;
+    xmat proj((size_t)N * N, 0.0L);
+    for (int i = 0; i < N; i++) proj[(size_t)i * N + i] = 1.0L;
     if (!rows.empty()) {
         const int m = (int)rows.size();
-        double G[2][2] = {{0, 0}, {0, 0}}, Gi[2][2];
+        xreal G[2][2] = {{0, 0}, {0, 0}}, Gi[2][2] = {{0, 0}, {0, 0}};
         for (int a = 0; a < m; a++)
             for (int b = 0; b < m; b++)
                 for (int k = 0; k < N; k++) G[a][b] += rows[a][k] * rows[b][k];
         if (m == 1) {
-            Gi[0][0] = 1.0 / G[0][0];
+            Gi[0][0] = 1.0L / G[0][0];
         } else {
-            double det = G[0][0] * G[1][1] - G[0][1] * G[1][0];
+            xreal det = G[0][0] * G[1][1] - G[0][1] * G[1][0];
             Gi[0][0] = G[1][1] / det; Gi[0][1] = -G[0][1] / det; Gi[1][0] = -G[1][0] / det; Gi[1][1] = G[0][0] / det;
         }
         for (int i = 0; i < N; i++)
             for (int j = 0; j < N; j++) {
-                double s = 0.0;
+                xreal s = 0.0L;
                 for (int a = 0; a < m; a++)
                     for (int b = 0; b < m; b++) s += rows[a][i] * Gi[a][b] * rows[b][j];
                 proj[(size_t)i * N + j] -= s;
             }
     }
-    o.CA.assign((size_t)N * Zb, 0.0);
+    xmat CA((size_t)N * Zb, 0.0L);
     for (int i = 0; i < N; i++)
-        for (int k = 0; k < Zb; k++) o.CA[(size_t)i * Zb + k] = proj[(size_t)i * N + k];
-    std::vector<double> TDc2;
-    matmul(o.T, o.CA, o.M[0], N, N, Zb);
-    matmul(TD, o.CA, o.M[1], N, N, Zb);
-    matmul(TDD, o.CA, o.M[2], N, N, Zb);
-    std::vector<double> TI, TICA;
-    matmul(o.T, Ic, TI, N, N, N);
-    matmul(TI, o.CA, TICA, N, N, Zb);
-    matmul(TICA, o.CB, o.Mint, N, Zb, N);
-    matmul(o.M[1], o.CB, o.Mdz, N, Zb, N);
-    matmul(o.M[0], o.CB, o.Mrec, N, Zb, N);
+        for (int k = 0; k < Zb; k++) CA[(size_t)i * Zb + k] = proj[(size_t)i * N + k];
+    xmat M0, M1, M2, TI, TICA, Mint, Mdz, Mrec;
+    matmul(x.T, CA, M0, N, N, Zb);
+    matmul(x.TD, CA, M1, N, N, Zb);
+    matmul(x.TDD, CA, M2, N, N, Zb);
+    matmul(x.T, Ic, TI, N, N, N);
+    matmul(TI, CA, TICA, N, N, Zb);
+    matmul(TICA, CB, Mint, N, Zb, N);
+    matmul(M1, CB, Mdz, N, Zb, N);
+    matmul(M0, CB, Mrec, N, Zb, N);
+    o.T = to_double(x.T); o.Dc = to_double(x.Dc); o.CB = to_double(CB); o.CA = to_double(CA);
+    o.M[0] = to_double(M0); o.M[1] = to_double(M1); o.M[2] = to_double(M2);
+    o.Mint = to_double(Mint); o.Mdz = to_double(Mdz); o.Mrec = to_double(Mrec);
+    o.zmin = zmin; o.zmax = zmax;
     return true;
 }
 
 bool build_helmholtz(const ChebOps &w, double pxi_bar, double tau, std::vector<double> &Wmat, std::vector<double> &Xmat,
                      std::string &err) {
     const int N = (int)w.z.size();
-    const double c = tau * tau * pxi_bar;
-    std::vector<double> TD, TDD;
-    matmul(w.T, w.Dc, TD, N, N, N);
-    matmul(TD, w.Dc, TDD, N, N, N);
+    const xreal c = (xreal)tau * (xreal)tau * (xreal)pxi_bar;
+    ChebX x;
+    cheb_factors(w.zmin, w.zmax, N, x);
     // H = [c T[0,:]; c T[N-1,:]; (c TDD - T)[1..N-2, :]]   (src/semiimplicit.jl:776-779)
-    std::vector<long double> H((size_t)N * N), Inv((size_t)N * N, 0.0L);
+    xmat H((size_t)N * N), Inv((size_t)N * N, 0.0L);
     for (int j = 0; j < N; j++) {
-        H[j] = c * w.T[j];
-        H[(size_t)N + j] = c * w.T[(size_t)(N - 1) * N + j];
-        for (int i = 1; i < N - 1; i++) H[(size_t)(i + 1) * N + j] = c * TDD[(size_t)i * N + j] - w.T[(size_t)i * N + j];
+        H[j] = c * x.T[j];
+        H[(size_t)N + j] = c * x.T[(size_t)(N - 1) * N + j];
+        for (int i = 1; i < N - 1; i++) H[(size_t)(i + 1) * N + j] = c * x.TDD[(size_t)i * N + j] - x.T[(size_t)i * N + j];
     }
     for (int i = 0; i < N; i++) Inv[(size_t)i * N + i] = 1.0L;
-    // Gauss-Jordan with partial pivoting in extended precision
+    // Gauss-Jordan with partial pivoting in extended precision (the reference factorises in double, :780)
     for (int col = 0; col < N; col++) {
         int piv = col;
         for (int r = col + 1; r < N; r++)
@@ -290,11 +312,11 @@ bool build_helmholtz(const ChebOps &w, double pxi_bar, double tau, std::vector<d
                 std::swap(H[(size_t)piv * N + j], H[(size_t)col * N + j]);
                 std::swap(Inv[(size_t)piv * N + j], Inv[(size_t)col * N + j]);
             }
-        long double d = 1.0L / H[(size_t)col * N + col];
+        xreal d = 1.0L / H[(size_t)col * N + col];
         for (int j = 0; j < N; j++) { H[(size_t)col * N + j] *= d; Inv[(size_t)col * N + j] *= d; }
         for (int r = 0; r < N; r++) {
             if (r == col) continue;
-            long double f = H[(size_t)r * N + col];
+            xreal f = H[(size_t)r * N + col];
             if (f == 0.0L) continue;
             for (int j = 0; j < N; j++) {
                 H[(size_t)r * N + j] -= f * H[(size_t)col * N + j];
@@ -302,18 +324,11 @@ bool build_helmholtz(const ChebOps &w, double pxi_bar, double tau, std::vector<d
             }
         }
     }
-    Wmat.assign((size_t)N * N, 0.0);
-    Xmat.assign((size_t)N * N, 0.0);
-    for (int i = 0; i < N; i++)
-        for (int j = 0; j < N; j++) {
-            long double sw = 0.0L, sx_ = 0.0L;
-            for (int k = 0; k < N; k++) {
-                sw += (long double)w.T[(size_t)i * N + k] * Inv[(size_t)k * N + j];
-                sx_ += (long double)TD[(size_t)i * N + k] * Inv[(size_t)k * N + j];
-            }
-            Wmat[(size_t)i * N + j] = (double)sw;
-            Xmat[(size_t)i * N + j] = (double)sx_;
-        }
+    xmat W, X;
+    matmul(x.T, Inv, W, N, N, N);
+    matmul(x.TD, Inv, X, N, N, N);
+    Wmat = to_double(W);
+    Xmat = to_double(X);
     return true;
 }
 

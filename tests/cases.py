@@ -203,3 +203,42 @@ def rel_err_per_var(a, b):
             elif diff > 0:
                 return np.inf
     return worst
+
+
+# ----------------------------------------------------------------------------- BASELINE.json configs at full size
+def config2_literal(twoway=False):
+    """configs[1]: models/cha_bell2024/Oneway_ShallowWater_Slab.jl verbatim (100 cells, native ragged rings,
+    N = 181,800) with the notebook's Rankine vortex + wave-2 perturbation (Cha_Bell_WCD2024_initialization.ipynb)."""
+    def ic(p):
+        r, l = p[:, 0], p[:, 1]
+        Rmax, Vmax, eps, f = 50000.0, 50.0, 5000.0, 5.0e-5
+        V0 = Vmax / Rmax
+        zeta = 2.0 * V0
+        vbar = np.where(r < Rmax, V0 * r, Rmax * Rmax * V0 / r)
+        # gradient-balanced height dh/dr = (f v + v^2 / r) / g in closed form (pointwise, so tiles can call it separately)
+        g = 9.81
+        h_in = (f * V0 + V0 * V0) * r * r / (2.0 * g)
+        h_rmax = (f * V0 + V0 * V0) * Rmax * Rmax / (2.0 * g)
+        rs = np.maximum(r, Rmax)
+        h_out = h_rmax + (f * Rmax ** 2 * V0 * np.log(rs / Rmax) + 0.5 * Rmax ** 4 * V0 ** 2 * (1.0 / Rmax ** 2 - 1.0 / rs ** 2)) / g
+        h = np.where(r < Rmax, h_in, h_out)
+        inner = r < Rmax
+        vp = np.where(inner, 0.5 * zeta * r * (eps * np.cos(2 * l) / Rmax),
+                      0.5 * zeta * (Rmax ** 2 / r) * (-eps * np.cos(2 * l) * Rmax / r ** 2))
+        up = np.where(inner, 0.5 * zeta * r * (eps * np.sin(2 * l) / Rmax),
+                      0.5 * zeta * (Rmax ** 2 / r) * (eps * np.sin(2 * l) * Rmax / r ** 2))
+        return np.stack([h, up, vbar + vp, 0.8 * up, 0.8 * (vbar + vp), 0.0 * r], axis=1)
+    par = dict(g=9.81, K=5000.0, Cd=2.4e-3, Hfree=2000.0, Hb=1000.0, f=5.0e-5, S1=1.0e-4)
+    return dict(name="config2", grid=dict(geometry="RL", xmin=0.0, xmax=3.0e5, num_cells=100, vars=VARS6, BCL=BCL6, BCR=BCR6),
+                eq="Twoway_ShallowWater_Slab" if twoway else "Oneway_ShallowWater_Slab", ts=3.0, par=par, ic=ic)
+
+
+def config3_rz(num_cells=171, zDim=128):
+    """configs[2]: RZ 513 x 128 with Chebyshev vertical (b_zDim = zDim) and the semi-implicit adjustment."""
+    c = rz_semiimplicit(num_cells=num_cells, zDim=zDim)
+    c["name"] = "config3"
+    # explicit horizontal acoustic CFL = sqrt(Pxi_bar) * ts / DX must stay below 1 (DX = 58 m here); the vertical one
+    # (min dz = 3 m, CFL ~ 11) is what the semi-implicit adjustment is for. With ts = 2 s the run is unstable and
+    # rounding differences between two correct implementations grow ~30x per step.
+    c["ts"] = 0.1
+    return c
