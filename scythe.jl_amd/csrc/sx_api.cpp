@@ -899,6 +899,7 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     }
     else if (k == "k_fl_forward") b = w * (N * V + fl);
     else if (k == "k_sb") b = w * (fl + bz);
+    else if (k == "k_sbz") b = w * (fl + S_tile);
     else if (k == "k_zf") b = w * (bz + S_tile);
     else if (k == "k_solve") b = w * 4.0 * S_patch;                 // read B, write y, read y, write A
     else if (k == "k_semiimplicit") b = w * N * 2.0 * 5.0;

@@ -207,6 +207,60 @@ __global__ void k_sb(const double *__restrict__ Fl, double *__restrict__ Bz, con
     Bz[(int64_t)j * plane + e] = s;
 }
 
+// ------------------------------------------------------------------------------------------------ radial inner products + vertical forward
+// Fused k_sb + vertical forward transform (RZ / RLZ): the [z][64 blocks] tile of radial inner products of node j stays in
+// LDS and is contracted with CB right away, so Bz never goes to HBM.
+//   B[j][v][zm][blk] = sum_z CB[zm][z] * sum_{rings of cells j-3..j} wq * phi0 * Fl[ring][v][z][blk]
+__global__ void __launch_bounds__(256)
+k_sbz(const double *__restrict__ Fl, double *__restrict__ B, const double *__restrict__ phi, const double *__restrict__ wq,
+      const double *__restrict__ CB, int ncells, int V, int nz, int Zb, int K2, int64_t C) {
+    extern __shared__ double As[];          // [nz][64]
+    const int lane = threadIdx.x;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.y);
+    const int blk = blockIdx.x * 64 + lane;
+    const int v = blockIdx.y, j = blockIdx.z;
+    const bool ok = blk < K2;
+    const int64_t plane = (int64_t)V * nz * K2;
+    const int c0 = max(0, j - 3), c1 = min(ncells - 1, j);
+    for (int z = g; z < nz; z += 4) {
+        double s = 0.0;
+        if (ok) {
+            const int64_t e = ((int64_t)v * nz + z) * K2 + blk;
+            for (int c = c0; c <= c1; c++) {
+                const int jj = j - c;
+#pragma unroll
+                for (int mu = 0; mu < MUBAR; mu++) {
+                    const int ring = c * MUBAR + mu;
+                    s += wq[ring] * phi[(int64_t)ring * 4 + jj] * Fl[(int64_t)ring * plane + e];
+                }
+            }
+        }
+        As[z * 64 + lane] = s;
+    }
+    __syncthreads();
+    double *dst = B + (int64_t)j * C + (int64_t)v * Zb * K2;
+    for (int o0 = g * 4; o0 < Zb; o0 += 16) {
+        const double *m0 = CB + (int64_t)o0 * nz;
+        const double *m1 = CB + (int64_t)min(o0 + 1, Zb - 1) * nz;
+        const double *m2 = CB + (int64_t)min(o0 + 2, Zb - 1) * nz;
+        const double *m3 = CB + (int64_t)min(o0 + 3, Zb - 1) * nz;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        for (int i = 0; i < nz; i++) {
+            const double x = As[i * 64 + lane];
+            a0 += m0[i] * x;
+            a1 += m1[i] * x;
+            a2 += m2[i] * x;
+            a3 += m3[i] * x;
+        }
+        if (ok) {
+            dst[(int64_t)o0 * K2 + blk] = a0;
+            if (o0 + 1 < Zb) dst[(int64_t)(o0 + 1) * K2 + blk] = a1;
+            if (o0 + 2 < Zb) dst[(int64_t)(o0 + 2) * K2 + blk] = a2;
+            if (o0 + 3 < Zb) dst[(int64_t)(o0 + 3) * K2 + blk] = a3;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ B -> A banded SPD solve
 // One lane per right-hand side (column); rows are contiguous across lanes so every load/store is coalesced.
 // a = Gamma^T (L L^T)^-1 Gamma b with L banded (half-bandwidth 3) plus, for PERIODIC, three dense last rows.
@@ -844,6 +898,16 @@ void launch_fl_forward(sx_handle *h) {
 }
 
 void launch_sb(sx_handle *h) {
+    if (h->has_z) {        // fused with the vertical forward transform; launch_zf is then a no-op
+        const int id = timer_id(h, "k_sbz");
+        timer_begin(h, id);
+        dim3 g((h->K2 + 63) / 64, h->V, h->nbt);
+        hipLaunchKernelGGL(k_sbz, g, dim3(64, 4), sizeof(double) * 64 * h->nz, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq,
+                           h->d_CB, h->ncells, h->V, h->nz, h->Zb, h->K2, h->C);
+        HIPCHK(hipGetLastError());
+        timer_end(h);
+        return;
+    }
     const int id = timer_id(h, "k_sb");
     timer_begin(h, id);
     const int64_t plane = (int64_t)h->V * h->nz * h->K2;
@@ -855,6 +919,7 @@ void launch_sb(sx_handle *h) {
 }
 
 void launch_zf(sx_handle *h) {
+    return;                // the vertical forward transform is fused into k_sbz (launch_sb)
     if (!h->has_z) return;
     const int id = timer_id(h, "k_zf");
     timer_begin(h, id);
