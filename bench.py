@@ -66,8 +66,9 @@ def grid_kwargs(workload):
 def cpu_baseline(workload, sample_cells, steps):
     """Time the C oracle (oracle/scythe_oracle.c, OpenMP) on a radial sample of the workload: `sample_cells` cells
     from the middle of the patch with the full azimuthal x vertical extent, plus the full-patch B->A solve."""
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))   # the box's CPU share for one GPU
     from oracle import oracle_np as O, oracle_c as OC
+    # the GPU box's CPU share for one GPU is 16 cores; an OMP_NUM_THREADS given by the caller wins
+    OC.lib().orc_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1))))
     kw, L = grid_kwargs(workload)
     g = O.Grid(kw.pop("geometry"), kw.pop("xmin"), kw.pop("xmax"), kw.pop("num_cells"), kw.pop("vars"), ring_L=L, **kw)
     c0 = (g.nc - sample_cells) // 2

@@ -59,6 +59,14 @@ typedef struct {
     const double *Larrow;  /* [nclass][3][b_rDim]   rows nfree-3..nfree-1 (periodic only) */
 } orc_grid;
 
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();
