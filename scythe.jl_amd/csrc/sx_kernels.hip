@@ -267,92 +267,102 @@ k_sbz(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
 // A wave covers 64 consecutive wavenumber blocks of one (variable, z-mode): its boundary-condition class is
 // wave-uniform, so the factor entries are scalar loads. The k = 0 column (its own class) is handled by one extra
 // block per (variable, z-mode) in which only lane 0 works.
-#define SOLVE_U 8
-__device__ __forceinline__ double brow(const double *__restrict__ B, const int64_t *__restrict__ oa,
-                                       const int64_t *__restrict__ ob, int m, int64_t col) {
-    double x = B[oa[m] + col];
+#define SOLVE_U 16
+// scalar / pair arithmetic so that one kernel body serves a lane that owns one column (k = 0) or the (Re, Im) pair of a
+// wavenumber (two independent right-hand sides moved as one 16-byte access)
+struct S1 { double x; };
+struct S2 { double x, y; };
+__device__ __forceinline__ S1 ld(const double *p, S1 *) { return S1{p[0]}; }
+__device__ __forceinline__ S2 ld(const double *p, S2 *) { const double2 v = *reinterpret_cast<const double2 *>(p); return S2{v.x, v.y}; }
+__device__ __forceinline__ void st(double *p, S1 v) { p[0] = v.x; }
+__device__ __forceinline__ void st(double *p, S2 v) { *reinterpret_cast<double2 *>(p) = make_double2(v.x, v.y); }
+__device__ __forceinline__ S1 operator+(S1 a, S1 b) { return S1{a.x + b.x}; }
+__device__ __forceinline__ S2 operator+(S2 a, S2 b) { return S2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ S1 operator-(S1 a, S1 b) { return S1{a.x - b.x}; }
+__device__ __forceinline__ S2 operator-(S2 a, S2 b) { return S2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ S1 operator*(double c, S1 a) { return S1{c * a.x}; }
+__device__ __forceinline__ S2 operator*(double c, S2 a) { return S2{c * a.x, c * a.y}; }
+__device__ __forceinline__ S1 zero(S1 *) { return S1{0.0}; }
+__device__ __forceinline__ S2 zero(S2 *) { return S2{0.0, 0.0}; }
+
+template <class T>
+__device__ __forceinline__ T brow(const double *__restrict__ B, const int64_t *__restrict__ oa, const int64_t *__restrict__ ob,
+                                  int m, int64_t col) {
+    T x = ld(B + oa[m] + col, (T *)nullptr);
     const int64_t o2 = ob[m];
-    if (o2 >= 0) x += B[o2 + col];
+    if (o2 >= 0) x = x + ld(B + o2 + col, (T *)nullptr);
     return x;
-}      // rows whose right-hand sides are fetched ahead of the dependent substitution chain
-__global__ void __launch_bounds__(64)
-k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA, const int64_t *__restrict__ boffB,
-        double *__restrict__ A, const int64_t *__restrict__ aoffA, const int64_t *__restrict__ aoffB,
-        const int *__restrict__ cls, const int *__restrict__ cmeta, const double *__restrict__ gl,
-        const double *__restrict__ gr, const double *__restrict__ Lband, const double *__restrict__ Ldinv,
-        const double *__restrict__ Larrow, int nb, int Zb, int K2, int vz0) {
-    // Row m of the right-hand side is Bsrc[boffA[m] + col] (+ Bsrc[boffB[m] + col] where a second tile overlaps, boffB >= 0);
-    // row m of the solution goes to A[aoffA[m] + col] and, in the final sweep, also to A[aoffB[m] + col] if aoffB >= 0.
-    const int vz = blockIdx.y;                      // local (v, zm) group; vz0 + vz is the patch-level group
-    const int v = (vz0 + vz) / Zb;
-    const int k0 = (blockIdx.x == gridDim.x - 1);   // the last block in x handles the k = 0 column
-    int blk;
-    if (k0) {
-        blk = 0;
-        if (threadIdx.x != 0) return;
-    } else {
-        blk = blockIdx.x * 64 + threadIdx.x;
-        if (blk >= K2 || (K2 > 1 && blk < 2)) return;            // block 0 -> k0 launch, block 1 is padding (stays zero)
-    }
-    const int64_t col = (int64_t)vz * K2 + blk;
-    const int c = cls[v * 2 + (k0 ? 0 : 1)];
+}
+
+// Row m of the right-hand side is Bsrc[boffA[m] + col] (+ Bsrc[boffB[m] + col] where a second tile overlaps, boffB >= 0);
+// row m of the solution goes to A[aoffA[m] + col] and, in the final sweep, also to A[aoffB[m] + col] if aoffB >= 0.
+template <class T, bool LINEAR>
+__device__ __forceinline__ void solve_columns(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA,
+                                              const int64_t *__restrict__ boffB, double *__restrict__ A,
+                                              const int64_t *__restrict__ aoffA, const int64_t *__restrict__ aoffB,
+                                              const int *__restrict__ cmeta, const double *__restrict__ gl,
+                                              const double *__restrict__ gr, const double *__restrict__ Lband,
+                                              const double *__restrict__ Ldinv, const double *__restrict__ Larrow, int nb, int c,
+                                              int64_t col, int64_t stride) {
     const int n = cmeta[c * 4 + 0], per = cmeta[c * 4 + 1], rl = cmeta[c * 4 + 2], rr = cmeta[c * 4 + 3];
     const double *Lb = Lband + (int64_t)c * nb * 4;
     const double *Ld = Ldinv + (int64_t)c * nb;
     const double *La = Larrow + (int64_t)c * 3 * nb;
     const double *g_l = gl + c * 6, *g_r = gr + c * 6;
-#define BROW(m) brow(Bsrc, boffA, boffB, (m), col)
-#define AROW(m) A[aoffA[m] + col]
-#define AFIN(m, val)                                    \
-    do {                                                \
-        const double v_ = (val);                        \
-        A[aoffA[m] + col] = v_;                         \
-        if (aoffB[m] >= 0) A[aoffB[m] + col] = v_;      \
+    T *tp = nullptr;
+    // LINEAR: one contiguous [row][col] array on each side (row offset = m * stride), no offset tables to fetch
+#define BROW(m) (LINEAR ? ld(Bsrc + (int64_t)(m) * stride + col, tp) : brow<T>(Bsrc, boffA, boffB, (m), col))
+#define AROW(m) ld(A + (LINEAR ? (int64_t)(m) * stride : aoffA[m]) + col, tp)
+#define ASET(m, val) st(A + (LINEAR ? (int64_t)(m) * stride : aoffA[m]) + col, (val))
+#define AFIN(m, val)                                                     \
+    do {                                                                 \
+        const T v_ = (val);                                              \
+        st(A + (LINEAR ? (int64_t)(m) * stride : aoffA[m]) + col, v_);   \
+        if (!LINEAR && aoffB[m] >= 0) st(A + aoffB[m] + col, v_);        \
     } while (0)
     if (!per) {
         // forward substitution; the free unknown i lives in row rl + i of A
-        double y1 = 0.0, y2 = 0.0, y3 = 0.0;     // y[i-1], y[i-2], y[i-3]
-        double bl0 = 0.0, bl1 = 0.0;
-        for (int q = 0; q < rl; q++) { const double bq = BROW(q); bl0 += g_l[q * 2] * bq; bl1 += g_l[q * 2 + 1] * bq; }
-        double br0 = 0.0, br1 = 0.0;
-        for (int q = 0; q < rr; q++) { const double bq = BROW(nb - 1 - q); br0 += g_r[q * 2] * bq; br1 += g_r[q * 2 + 1] * bq; }
+        T y1 = zero(tp), y2 = zero(tp), y3 = zero(tp);     // y[i-1], y[i-2], y[i-3]
+        T bl0 = zero(tp), bl1 = zero(tp), br0 = zero(tp), br1 = zero(tp);
+        for (int q = 0; q < rl; q++) { const T bq = BROW(q); bl0 = bl0 + g_l[q * 2] * bq; bl1 = bl1 + g_l[q * 2 + 1] * bq; }
+        for (int q = 0; q < rr; q++) { const T bq = BROW(nb - 1 - q); br0 = br0 + g_r[q * 2] * bq; br1 = br1 + g_r[q * 2 + 1] * bq; }
         for (int i0 = 0; i0 < n; i0 += SOLVE_U) {
-            double rhs[SOLVE_U];
+            T rhs[SOLVE_U];
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) rhs[u] = (i0 + u < n) ? BROW(rl + i0 + u) : 0.0;
+            for (int u = 0; u < SOLVE_U; u++) rhs[u] = (i0 + u < n) ? BROW(rl + i0 + u) : zero(tp);
 #pragma unroll
             for (int u = 0; u < SOLVE_U; u++) {
                 const int i = i0 + u;
                 if (i < n) {
-                    double s = rhs[u];
-                    if (i == 0) s += bl0;
-                    if (i == 1) s += bl1;
-                    if (i == n - 1) s += br0;
-                    if (i == n - 2) s += br1;
+                    T s = rhs[u];
+                    if (i == 0) s = s + bl0;
+                    if (i == 1) s = s + bl1;
+                    if (i == n - 1) s = s + br0;
+                    if (i == n - 2) s = s + br1;
                     const double *l = Lb + (int64_t)i * 4;
-                    s -= l[2] * y1 + l[1] * y2 + l[0] * y3;
-                    s *= Ld[i];
+                    s = s - (l[2] * y1 + l[1] * y2 + l[0] * y3);
+                    s = Ld[i] * s;
                     y3 = y2; y2 = y1; y1 = s;
-                    AROW(rl + i) = s;
+                    ASET(rl + i, s);
                 }
             }
         }
         // back substitution
-        double x1 = 0.0, x2 = 0.0, x3 = 0.0;     // x[i+1], x[i+2], x[i+3]
-        double xl0 = 0.0, xl1 = 0.0, xr0 = 0.0, xr1 = 0.0;
+        T x1 = zero(tp), x2 = zero(tp), x3 = zero(tp);     // x[i+1], x[i+2], x[i+3]
+        T xl0 = zero(tp), xl1 = zero(tp), xr0 = zero(tp), xr1 = zero(tp);
         for (int i0 = n - 1; i0 >= 0; i0 -= SOLVE_U) {
-            double rhs[SOLVE_U];
+            T rhs[SOLVE_U];
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) rhs[u] = (i0 - u >= 0) ? AROW(rl + i0 - u) : 0.0;
+            for (int u = 0; u < SOLVE_U; u++) rhs[u] = (i0 - u >= 0) ? AROW(rl + i0 - u) : zero(tp);
 #pragma unroll
             for (int u = 0; u < SOLVE_U; u++) {
                 const int i = i0 - u;
                 if (i >= 0) {
-                    double s = rhs[u];
-                    if (i + 1 < n) s -= Lb[(int64_t)(i + 1) * 4 + 2] * x1;
-                    if (i + 2 < n) s -= Lb[(int64_t)(i + 2) * 4 + 1] * x2;
-                    if (i + 3 < n) s -= Lb[(int64_t)(i + 3) * 4 + 0] * x3;
-                    s *= Ld[i];
+                    T s = rhs[u];
+                    if (i + 1 < n) s = s - Lb[(int64_t)(i + 1) * 4 + 2] * x1;
+                    if (i + 2 < n) s = s - Lb[(int64_t)(i + 2) * 4 + 1] * x2;
+                    if (i + 3 < n) s = s - Lb[(int64_t)(i + 3) * 4 + 0] * x3;
+                    s = Ld[i] * s;
                     x3 = x2; x2 = x1; x1 = s;
                     AFIN(rl + i, s);
                     if (i == n - 1) xr0 = s;
@@ -366,40 +376,40 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA, cons
         for (int q = 0; q < rr; q++) AFIN(nb - 1 - q, g_r[q * 2] * xr0 + g_r[q * 2 + 1] * xr1);
     } else {
         // periodic: unknown i <-> row i + 1; rows 0, nb-2, nb-1 fold onto unknowns n-1, 0, 1
-        double y1 = 0.0, y2 = 0.0, y3 = 0.0;
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;        // arrow-row dot products
+        T y1 = zero(tp), y2 = zero(tp), y3 = zero(tp);
+        T acc0 = zero(tp), acc1 = zero(tp), acc2 = zero(tp);        // arrow-row dot products
         for (int i = 0; i < n - 3; i++) {
-            double s = BROW(i + 1);
-            if (i == 0) s += BROW(nb - 2);
-            if (i == 1) s += BROW(nb - 1);
+            T s = BROW(i + 1);
+            if (i == 0) s = s + BROW(nb - 2);
+            if (i == 1) s = s + BROW(nb - 1);
             const double *l = Lb + (int64_t)i * 4;
-            s -= l[2] * y1 + l[1] * y2 + l[0] * y3;
-            s *= Ld[i];
+            s = s - (l[2] * y1 + l[1] * y2 + l[0] * y3);
+            s = Ld[i] * s;
             y3 = y2; y2 = y1; y1 = s;
-            AROW(i + 1) = s;
-            acc0 += La[i] * s;
-            acc1 += La[nb + i] * s;
-            acc2 += La[2 * nb + i] * s;
+            ASET(i + 1, s);
+            acc0 = acc0 + La[i] * s;
+            acc1 = acc1 + La[nb + i] * s;
+            acc2 = acc2 + La[2 * nb + i] * s;
         }
-        double t0 = (BROW(n - 2) - acc0) / La[n - 3];
-        double t1 = (BROW(n - 1) - acc1 - La[nb + n - 3] * t0) / La[nb + n - 2];
-        double t2 = (BROW(n) + BROW(0) - acc2 - La[2 * nb + n - 3] * t0 - La[2 * nb + n - 2] * t1) / La[2 * nb + n - 1];
+        const T t0 = (1.0 / La[n - 3]) * (BROW(n - 2) - acc0);
+        const T t1 = (1.0 / La[nb + n - 2]) * (BROW(n - 1) - acc1 - La[nb + n - 3] * t0);
+        const T t2 = (1.0 / La[2 * nb + n - 1]) * (BROW(n) + BROW(0) - acc2 - La[2 * nb + n - 3] * t0 - La[2 * nb + n - 2] * t1);
         // back substitution of the dense 3x3 corner
-        const double u2 = t2 / La[2 * nb + n - 1];
-        const double u1 = (t1 - La[2 * nb + n - 2] * u2) / La[nb + n - 2];
-        const double u0 = (t0 - La[nb + n - 3] * u1 - La[2 * nb + n - 3] * u2) / La[n - 3];
+        const T u2 = (1.0 / La[2 * nb + n - 1]) * t2;
+        const T u1 = (1.0 / La[nb + n - 2]) * (t1 - La[2 * nb + n - 2] * u2);
+        const T u0 = (1.0 / La[n - 3]) * (t0 - La[nb + n - 3] * u1 - La[2 * nb + n - 3] * u2);
         AFIN(n - 2, u0);
         AFIN(n - 1, u1);
         AFIN(n, u2);
-        double x1 = 0.0, x2 = 0.0, x3 = 0.0;
-        double first0 = 0.0, first1 = 0.0;
+        T x1 = zero(tp), x2 = zero(tp), x3 = zero(tp);
+        T first0 = zero(tp), first1 = zero(tp);
         for (int i = n - 4; i >= 0; i--) {
-            double s = AROW(i + 1);
-            if (i + 1 < n - 3) s -= Lb[(int64_t)(i + 1) * 4 + 2] * x1;
-            if (i + 2 < n - 3) s -= Lb[(int64_t)(i + 2) * 4 + 1] * x2;
-            if (i + 3 < n - 3) s -= Lb[(int64_t)(i + 3) * 4 + 0] * x3;
-            s -= La[i] * u0 + La[nb + i] * u1 + La[2 * nb + i] * u2;
-            s *= Ld[i];
+            T s = AROW(i + 1);
+            if (i + 1 < n - 3) s = s - Lb[(int64_t)(i + 1) * 4 + 2] * x1;
+            if (i + 2 < n - 3) s = s - Lb[(int64_t)(i + 2) * 4 + 1] * x2;
+            if (i + 3 < n - 3) s = s - Lb[(int64_t)(i + 3) * 4 + 0] * x3;
+            s = s - (La[i] * u0 + La[nb + i] * u1 + La[2 * nb + i] * u2);
+            s = Ld[i] * s;
             x3 = x2; x2 = x1; x1 = s;
             AFIN(i + 1, s);
             if (i == 0) first0 = s;
@@ -411,7 +421,34 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA, cons
     }
 #undef BROW
 #undef AROW
+#undef ASET
 #undef AFIN
+}
+
+// One lane per wavenumber: the (Re, Im) columns of a wavenumber k >= 1 form one 16-byte aligned pair and share a
+// boundary-condition class, so a lane solves both with double2 loads/stores; rows are contiguous across lanes, so every
+// access is coalesced. The k = 0 column (own class, single column) is handled by one extra block per (variable,
+// z-mode) in which only lane 0 works.
+template <bool LINEAR>
+__global__ void __launch_bounds__(64)
+k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA, const int64_t *__restrict__ boffB,
+        double *__restrict__ A, const int64_t *__restrict__ aoffA, const int64_t *__restrict__ aoffB,
+        const int *__restrict__ cls, const int *__restrict__ cmeta, const double *__restrict__ gl,
+        const double *__restrict__ gr, const double *__restrict__ Lband, const double *__restrict__ Ldinv,
+        const double *__restrict__ Larrow, int nb, int Zb, int K2, int vz0, int64_t stride) {
+    const int vz = blockIdx.y;                      // local (v, zm) group; vz0 + vz is the patch-level group
+    const int v = (vz0 + vz) / Zb;
+    const bool k0 = (blockIdx.x == gridDim.x - 1);  // the last block in x handles the k = 0 column
+    if (k0) {
+        if (threadIdx.x != 0) return;
+        solve_columns<S1, LINEAR>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 0],
+                                  (int64_t)vz * K2, stride);
+    } else {
+        const int k = 1 + blockIdx.x * 64 + threadIdx.x;      // wavenumber; its columns are blocks 2k and 2k + 1
+        if (2 * k + 1 >= K2) return;
+        solve_columns<S2, LINEAR>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 1],
+                                  (int64_t)vz * K2 + 2 * k, stride);
+    }
 }
 
 // Transposed (all-to-all) patch solve, tile side: split the tile's [row][col] arrays by destination column range.
@@ -933,9 +970,15 @@ void launch_zf(sx_handle *h) {
 void launch_solve(sx_handle *h) {
     const int id = timer_id(h, "k_solve");
     timer_begin(h, id);
-    dim3 g((h->K2 > 1 ? (h->K2 + 63) / 64 : 0) + 1, h->V * h->Zb);
-    hipLaunchKernelGGL(k_solve, g, dim3(64), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff, h->d_neg1, h->d_cls,
-                       h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2, 0);
+    dim3 g((h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1, h->V * h->Zb);
+    if (h->d_Bsrc == h->d_Bfull)     // internal contiguous B: no offset tables needed
+        hipLaunchKernelGGL(k_solve<true>, g, dim3(64), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff, h->d_neg1,
+                           h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2, 0,
+                           h->C);
+    else
+        hipLaunchKernelGGL(k_solve<false>, g, dim3(64), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff,
+                           h->d_neg1, h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb,
+                           h->K2, 0, h->C);
     HIPCHK(hipGetLastError());
     timer_end(h);
 }
@@ -947,10 +990,10 @@ void launch_solve_a2a(sx_handle *h, const double *recv, double *send) {
     timer_begin(h, id);
     const int ng = h->a2a_g1 - h->a2a_g0;
     if (ng > 0) {
-        dim3 g((h->K2 > 1 ? (h->K2 + 63) / 64 : 0) + 1, ng);
-        hipLaunchKernelGGL(k_solve, g, dim3(64), 0, h->stream, recv, h->d_a2a_offA, h->d_a2a_offB, send, h->d_a2a_offA, h->d_a2a_offB,
-                           h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2,
-                           h->a2a_g0);
+        dim3 g((h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1, ng);
+        hipLaunchKernelGGL(k_solve<false>, g, dim3(64), 0, h->stream, recv, h->d_a2a_offA, h->d_a2a_offB, send, h->d_a2a_offA,
+                           h->d_a2a_offB, h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb,
+                           h->K2, h->a2a_g0, (int64_t)0);
         HIPCHK(hipGetLastError());
     }
     timer_end(h);
