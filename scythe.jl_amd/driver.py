@@ -309,15 +309,13 @@ def integrate_model(model: ModelParameters, num_tiles=1, verbose=False):
             print("ts: %s" % (t * model.ts), file=log)
         run.step()
         if output_int > 0 and t % output_int == 0 and t != num_ts:
-            for g in run.tiles:
-                g.tileTransform_()
-                checkCFL(g)
             write_output(run, model, t * model.ts)
+            for g in run.tiles:
+                checkCFL(g)
     print("%.6f seconds" % (time.time() - t0), file=log)
-    for g in run.tiles:
-        g.tileTransform_()
-        checkCFL(g)
     write_output(run, model, model.integration_time)
+    for g in run.tiles:
+        checkCFL(g)
     print("Model complete!", file=log)
     log.close()
     run.close()

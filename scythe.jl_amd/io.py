@@ -35,6 +35,7 @@ def write_output(run, model, time):
     path = os.path.join(model.output_dir, "physical_out_%s.csv" % float(time))
     rows = []
     for g in run.tiles:
+        g.tileTransform_()          # patch.spectral -> physical before every output (src/semiimplicit.jl:241, 290)
         pts = getGridpoints(g)
         pts = pts.reshape(len(pts), -1)
         rows.append(np.concatenate([pts, g.physical[:, :, 0]], axis=1))

@@ -45,3 +45,28 @@ def test_patch_layout_row_ownership():
     # every patch row is owned exactly once; rows of tile t live in slot t of the gather buffer
     assert len(set(off.tolist())) == 13
     assert list(off[:4] // 7) == [0, 1, 2, 3] and list(off[4:7] // 7) == [7, 8, 9] and list(off[7:] // 7) == [14, 15, 16, 17, 18, 19]
+
+
+def test_csv_reader_matches_notebook_format(tmp_path):
+    """read_physical_grid picks variables by column name from the CSV the notebook writes (r,u / r,l,h,u,v,...)."""
+    from scythe_jl_amd.io import read_physical_grid
+
+    class FakeTile:
+        def __init__(self, n):
+            self.N = n
+
+    class FakeRun:
+        num_tiles = 2
+        tiles = [FakeTile(4), FakeTile(2)]
+        tile_ids = [0, 1]
+
+        class layout:
+            tile_sizes = np.array([[0, 0], [0, 0], [0, 0], [0, 0], [4, 2]], dtype=float)
+
+    gp = S.GridParameters(geometry="RL", xmin=0.0, xmax=1.0, num_cells=6, vars={"h": 1, "u": 2})
+    path = tmp_path / "ic.csv"
+    data = np.arange(24, dtype=float).reshape(6, 4)
+    np.savetxt(path, data, delimiter=",", header="r,l,u,h", comments="")      # columns in a different order than vars
+    vals = read_physical_grid(str(path), gp, FakeRun)
+    assert [v.shape for v in vals] == [(4, 2), (2, 2)]
+    assert np.array_equal(vals[0][:, 0], data[:4, 3]) and np.array_equal(vals[1][:, 1], data[4:, 2])
