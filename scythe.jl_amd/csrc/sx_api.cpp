@@ -2,6 +2,7 @@
 #include "sx_internal.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <type_traits>
@@ -483,6 +484,33 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
             h->mask_eq_bits += __builtin_popcount(eq[v]);
         }
         if (!upload(h, &h->d_mask_full, full) || !upload(h, &h->d_mask_eq, eq)) FAIL();
+        // node-space ("radial last") inverse: uniform power-of-two rings + the MFMA HRBL kernel
+        if (h->eq == SX_EQ_ONEWAY_SW_HRBL && h->V == 6 && fft_path_ok(h) && h->has_z && (h->nz == 64 || h->nz == 32) &&
+            !(getenv("SX_NODE_MODE") && atoi(getenv("SX_NODE_MODE")) == 0)) {
+            h->node_mode = 1;
+            h->R_in = 0;
+            while (h->R_in < h->nrings && h->hkmax[h->R_in] < h->kDim) h->R_in++;
+            for (int i = h->R_in; i < h->nrings; i++)
+                if (h->hkmax[i] != h->kDim) h->node_mode = 0;          // truncation must be ring-independent beyond R_in
+            if (h->R_in == h->nrings) h->node_mode = 0;                // no ring on the node-space path
+        }
+        if (h->node_mode) {
+            const int L = h->uniform_L;
+            h->NG = (int64_t)h->nbt * L * h->nz;
+            std::vector<int> nkmax(h->nbt, h->kDim), nmask(h->V, 0);
+            std::vector<int64_t> npstart(h->nbt), nphoff(h->nbt, phoff[h->nrings - 1]);   // zero phase offset: all (1, 0)
+            std::vector<double> nphi((size_t)3 * h->nbt * 4, 0.0);
+            for (int j = 0; j < h->nbt; j++) { npstart[j] = (int64_t)j * L; nphi[(size_t)j * 4] = 1.0; }
+            for (int v = 0; v < h->V; v++) {
+                if (eq[v] & (u | r | rr)) nmask[v] |= u;
+                nmask[v] |= eq[v] & (l | ll | z | zz);
+                h->mask_node_bits += __builtin_popcount(nmask[v]);
+            }
+            if (!upload(h, &h->d_nkmax, nkmax) || !upload(h, &h->d_npstart, npstart) || !upload(h, &h->d_nphoff, nphoff) ||
+                !upload(h, &h->d_nphi, nphi) || !upload(h, &h->d_mask_node, nmask) ||
+                !dalloc(h, &h->d_G, (size_t)h->D * h->V * h->NG))
+                FAIL();
+        }
         if (h->has_z) {   // vertical-transform job lists: only the (variable, operator) pairs some requested slot needs
             const int horiz = u | r | rr | l | ll;
             std::vector<ColJob> jf, je, jz;
@@ -889,7 +917,13 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     double b = 0;
     const double planes = h->last_mask_full ? h->mask_full_bits : h->mask_eq_bits;   // (variable, slot) planes produced
     (void)D;
-    if (k == "k_rl_inverse") b = w * (N * planes + az);             // write the requested physical planes, read Az
+    const bool node = h->node_mode && h->node_active;
+    const double fin = node ? (double)h->R_in / h->nrings : 1.0;   // fraction of rings on the ring-wise path
+    if (k == "k_rl_inverse") b = w * (N * planes + az) * fin;       // write the requested physical planes, read Az
+    else if (k == "k_node_fft") b = w * ((double)h->NG * h->mask_node_bits + az);
+    else if (k == "k_phys_hrbl_inner") b = w * N * fin * (h->mask_eq_bits + 4.0 * V - 2.0);
+    else if (k == "k_phys_hrbl" && node)                            // node transforms (read once) + history + outputs
+        b = w * ((double)h->NG * h->mask_node_bits + N * (1.0 - fin) * (4.0 * V - 2.0));
     else if (k == "k_zinv") b = w * (S_tile + az);
     else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") {
         // read the requested slots, E_nm1, E_nm2; write E_n, var_np1; the SW sets also write the diagnostic w plane and

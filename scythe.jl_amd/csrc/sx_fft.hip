@@ -128,7 +128,9 @@ k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,
                  int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
-                 int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz) {
+                 int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz, int node_mode) {
+    // node_mode: the "rings" are radial NODES (uniform ring tables only): one Az row per unit, no radial combination;
+    // the output is the node-space array G that the equation-set kernel combines with the basis weights itself.
     constexpr int L = 1 << LOGL, T = L / 4;
     extern __shared__ double2 smf[];
     const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * FZC;
@@ -143,7 +145,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const
     int par = 0;
     Twiddles<LOGL> tw;
     tw.template init<+1>(twg, t);
-    const int j0 = ring / MUBAR;
+    const int j0 = node_mode ? ring : ring / MUBAR;
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int mask = slotmask[v];
@@ -168,7 +170,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const
             const double *a0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + za)) * K2;
             const double *b0 = a0 + (hasb ? K2 : 0);
 #pragma unroll 2
-            for (int r = 0; r < 4; r++) {
+            for (int r = 0; r < (node_mode ? 1 : 4); r++) {
                 const double fr = pf[r];
                 if (in1) {
                     const double2 x = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * k1);
@@ -300,18 +302,37 @@ bool fft_path_ok(const sx_handle *h) {
 static size_t fft_lds(int L, int sets = 1) { return sizeof(double2) * (size_t)sets * FNP * (L + SKEW); }
 static int fft_threads(int L) { return std::max(64, FNP * (L / 4)); }
 
+struct InvTarget {          // where an inverse ring launch writes and which unit tables it uses
+    double *out;            // physical [slot][v][N] or node-space G [slot][v][NG]
+    const double *phi;      // [3][n_phi][4]
+    const int *kmax;
+    const int64_t *pstart, *phoff;
+    int n_units, n_phi;     // units launched (rings or nodes), ring count of the phi table
+    int64_t N;              // plane size of `out`
+    int node_mode;
+};
+
 template <int LOGL>
-static void launch_inv(sx_handle *h, const int *d_mask, dim3 g, const double *az, int64_t azrow) {
+static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, const double *az, int64_t azrow) {
     const int L = 1 << LOGL;
-    static const int copyout = getenv("SX_FFT_COPYOUT") ? atoi(getenv("SX_FFT_COPYOUT")) : 1;
-    if (copyout)
-        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az, h->d_phys, h->d_phi,
-                           h->d_kmax, h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, h->nrings,
-                           h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);
-    else
-        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 0>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, az, h->d_phys, h->d_phi,
-                           h->d_kmax, h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, h->nrings,
-                           h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);
+    dim3 g((h->nz + FZC - 1) / FZC, h->V, tg.n_units);
+    hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az, tg.out, tg.phi, tg.kmax,
+                       tg.pstart, h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],
+                       h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6], tg.node_mode);
+}
+
+static void launch_inv_any(sx_handle *h, const int *d_mask, const InvTarget &tg) {
+    if (tg.n_units <= 0) return;
+    const double *az = h->has_z ? h->d_Az : h->d_A + (int64_t)h->cell0 * h->C;
+    const int64_t azrow = h->has_z ? (int64_t)h->V * 3 * h->nz * h->K2 : h->C;
+    switch (ilog2(h->uniform_L)) {
+        case 4: launch_inv<4>(h, d_mask, tg, az, azrow); break;
+        case 5: launch_inv<5>(h, d_mask, tg, az, azrow); break;
+        case 6: launch_inv<6>(h, d_mask, tg, az, azrow); break;
+        case 7: launch_inv<7>(h, d_mask, tg, az, azrow); break;
+        default: launch_inv<8>(h, d_mask, tg, az, azrow); break;
+    }
+    HIPCHK2(hipGetLastError());
 }
 
 template <int LOGL>
@@ -321,20 +342,21 @@ static void launch_fwd(sx_handle *h, dim3 g) {
                        h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N);
 }
 
-void launch_rl_inverse_fft(sx_handle *h, const int *d_mask) {
+// ring-wise inverse of the first n_rings rings of the tile (all of them by default)
+void launch_rl_inverse_fft(sx_handle *h, const int *d_mask, int n_rings) {
     const int id = timer_id(h, "k_rl_inverse");
     timer_begin(h, id);
-    const double *az = h->has_z ? h->d_Az : h->d_A + (int64_t)h->cell0 * h->C;
-    const int64_t azrow = h->has_z ? (int64_t)h->V * 3 * h->nz * h->K2 : h->C;
-    dim3 g((h->nz + FZC - 1) / FZC, h->V, h->nrings);
-    switch (ilog2(h->uniform_L)) {
-        case 4: launch_inv<4>(h, d_mask, g, az, azrow); break;
-        case 5: launch_inv<5>(h, d_mask, g, az, azrow); break;
-        case 6: launch_inv<6>(h, d_mask, g, az, azrow); break;
-        case 7: launch_inv<7>(h, d_mask, g, az, azrow); break;
-        default: launch_inv<8>(h, d_mask, g, az, azrow); break;
-    }
-    HIPCHK2(hipGetLastError());
+    InvTarget tg{h->d_phys, h->d_phi, h->d_kmax, h->d_pstart, h->d_phoff, n_rings < 0 ? h->nrings : n_rings, h->nrings, h->N, 0};
+    launch_inv_any(h, d_mask, tg);
+    timer_end(h);
+}
+
+// node-space inverse ("radial last", uniform rings): one transform set per radial node instead of per ring
+void launch_node_fft(sx_handle *h) {
+    const int id = timer_id(h, "k_node_fft");
+    timer_begin(h, id);
+    InvTarget tg{h->d_G, h->d_nphi, h->d_nkmax, h->d_npstart, h->d_nphoff, h->nbt, h->nbt, h->NG, 1};
+    launch_inv_any(h, h->d_mask_node, tg);
     timer_end(h);
 }
 

@@ -108,6 +108,13 @@ struct sx_handle {
     int *d_mask_full = nullptr, *d_mask_eq = nullptr;   // per-variable bit masks of derivative slots to produce
     int mask_eq_bits = 0, mask_full_bits = 0;            // total number of (variable, slot) planes in each mask
     bool last_mask_full = true;
+    // node-space ("radial last") inverse for uniform rings: rings [0, R_in) keep the ring-wise path (their wavenumber
+    // truncation depends on the ring), rings [R_in, nrings) are evaluated from node-space transforms inside the equation set
+    int node_mode = 0, node_active = 0, R_in = 0, mask_node_bits = 0;
+    int64_t NG = 0;
+    double *d_G = nullptr, *d_nphi = nullptr;
+    int *d_nkmax = nullptr, *d_mask_node = nullptr;
+    int64_t *d_npstart = nullptr, *d_nphoff = nullptr;
     sx::ColJob *d_jobs_zinv_full = nullptr, *d_jobs_zinv_eq = nullptr, *d_jobs_zf = nullptr;
     int njobs_zinv_full = 0, njobs_zinv_eq = 0, last_zinv_jobs = 0;
     int ncls = 0;
@@ -125,7 +132,8 @@ namespace sx {
 void launch_zinv(sx_handle *h, bool full);
 void launch_rl_inverse(sx_handle *h, bool full);
 bool fft_path_ok(const sx_handle *h);
-void launch_rl_inverse_fft(sx_handle *h, const int *d_mask);
+void launch_rl_inverse_fft(sx_handle *h, const int *d_mask, int n_rings = -1);
+void launch_node_fft(sx_handle *h);
 void launch_fl_forward_fft(sx_handle *h);
 void launch_physics(sx_handle *h, int t);
 void launch_copy_slot0(sx_handle *h);

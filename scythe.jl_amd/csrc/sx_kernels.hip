@@ -494,6 +494,11 @@ struct PhysArgs {
     int s_u, s_r, s_rr, s_l, s_ll, s_z, s_zz;
     double ts;
     double par[SX_NPARAMS];
+    // column range of this launch and, for the node-space variant, the node transforms G [slot][v][NG] + basis weights
+    int64_t col0, col1;
+    const double *G, *phi;
+    int64_t NG;
+    int L, nrings;
 };
 
 // A diagnostic variable has expdot == 0 for ever (src/shallowWaterModels.jl:69, 185, 430): explicit_timestep reduces to
@@ -676,16 +681,19 @@ __global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgs a, int cpb) {
 // (L2-resident) operator, B and the result tiles live in LDS, column-major with a 2-double pad (bank-conflict free).
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-template <int NZ>
+// NODE = true ("radial last", uniform rings): instead of reading ring-wise derivative slots from `physical`, the thread
+// combines the node-space transforms G of the ring's 4 spline nodes with the basis weights phi, phi', phi'' itself
+// (value / d/dr / d2/dr2 from the value transform; d/dlambda, d2/dlambda2, d/dz from their own transforms), so the
+// 22 physical planes of these rings are never written to or read from HBM.
+template <int NZ, bool NODE>
 __global__ void __launch_bounds__(16 * NZ) k_phys_hrbl_mfma(PhysArgs a) {
     constexpr int CPB = 16, CS = NZ + 2;           // columns per block, column stride in LDS
     __shared__ double X[3][CPB * CS];              // div, Kv*ubz, Kv*vbz   -> inputs
     __shared__ double Y[3][CPB * CS];              // wb,  d/dz(...), d/dz(...) -> outputs
     __shared__ double s1[2][CPB];                  // ub, vb at level 1 ("10 m")
     const int k = threadIdx.x % NZ, cl = threadIdx.x / NZ;
-    const int64_t ncol = a.N / NZ;
-    const int64_t col = (int64_t)blockIdx.x * CPB + cl;
-    const bool live = col < ncol;
+    const int64_t col = a.col0 + (int64_t)blockIdx.x * CPB + cl;
+    const bool live = col < a.col1;
     const double *par = a.par;
     const double g = par[SX_P_G], Kh = par[SX_P_KH], Hfree = par[SX_P_HFREE], f = par[SX_P_F];
     const int64_t p = live ? col * NZ + k : 0;
@@ -694,11 +702,38 @@ __global__ void __launch_bounds__(16 * NZ) k_phys_hrbl_mfma(PhysArgs a) {
     double xd = 0.0, xu = 0.0, xv = 0.0;
     if (live) {
         r = a.r[col];
-        h = PS(0, a.s_u); hr = PS(0, a.s_r); hl = PS(0, a.s_l);
-        ug = PS(1, a.s_u); ugr = PS(1, a.s_r); ugl = PS(1, a.s_l);
-        vg = PS(2, a.s_u); vgr = PS(2, a.s_r); vgl = PS(2, a.s_l);
-        ub = PS(3, a.s_u); ubr = PS(3, a.s_r); ubrr = PS(3, a.s_rr); ubl = PS(3, a.s_l); ubll = PS(3, a.s_ll); ubz = PS(3, a.s_z);
-        vb = PS(4, a.s_u); vbr = PS(4, a.s_r); vbrr = PS(4, a.s_rr); vbl = PS(4, a.s_l); vbll = PS(4, a.s_ll); vbz = PS(4, a.s_z);
+        if (NODE) {
+            const int ring = (int)(col / a.L);
+            const int lam = (int)(col - (int64_t)ring * a.L);
+            const int64_t gp = ((int64_t)(ring / MUBAR) * a.L + lam) * NZ + k;      // node row of the ring's cell, this (lambda, z)
+            const int64_t gs = (int64_t)a.L * NZ;                                   // stride between nodes
+            const double *w0 = a.phi + (int64_t)ring * 4, *w1 = w0 + (int64_t)a.nrings * 4, *w2 = w1 + (int64_t)a.nrings * 4;
+            const double p00 = w0[0], p01 = w0[1], p02 = w0[2], p03 = w0[3];
+            const double p10 = w1[0], p11 = w1[1], p12 = w1[2], p13 = w1[3];
+            const double p20 = w2[0], p21 = w2[1], p22 = w2[2], p23 = w2[3];
+#define GN(v, s, j) a.G[((int64_t)(s) * a.V + (v)) * a.NG + gp + (j) * gs]
+#define NODE3(v, val, dr) { const double q0 = GN(v, a.s_u, 0), q1 = GN(v, a.s_u, 1), q2 = GN(v, a.s_u, 2), q3 = GN(v, a.s_u, 3); \
+                            val = p00 * q0 + p01 * q1 + p02 * q2 + p03 * q3; dr = p10 * q0 + p11 * q1 + p12 * q2 + p13 * q3; }
+#define NODE4(v, val, dr, drr) { const double q0 = GN(v, a.s_u, 0), q1 = GN(v, a.s_u, 1), q2 = GN(v, a.s_u, 2), q3 = GN(v, a.s_u, 3); \
+                            val = p00 * q0 + p01 * q1 + p02 * q2 + p03 * q3; dr = p10 * q0 + p11 * q1 + p12 * q2 + p13 * q3;    \
+                            drr = p20 * q0 + p21 * q1 + p22 * q2 + p23 * q3; }
+#define NODE1(v, s) (p00 * GN(v, s, 0) + p01 * GN(v, s, 1) + p02 * GN(v, s, 2) + p03 * GN(v, s, 3))
+            NODE3(0, h, hr); hl = NODE1(0, a.s_l);
+            NODE3(1, ug, ugr); ugl = NODE1(1, a.s_l);
+            NODE3(2, vg, vgr); vgl = NODE1(2, a.s_l);
+            NODE4(3, ub, ubr, ubrr); ubl = NODE1(3, a.s_l); ubll = NODE1(3, a.s_ll); ubz = NODE1(3, a.s_z);
+            NODE4(4, vb, vbr, vbrr); vbl = NODE1(4, a.s_l); vbll = NODE1(4, a.s_ll); vbz = NODE1(4, a.s_z);
+#undef GN
+#undef NODE3
+#undef NODE4
+#undef NODE1
+        } else {
+            h = PS(0, a.s_u); hr = PS(0, a.s_r); hl = PS(0, a.s_l);
+            ug = PS(1, a.s_u); ugr = PS(1, a.s_r); ugl = PS(1, a.s_l);
+            vg = PS(2, a.s_u); vgr = PS(2, a.s_r); vgl = PS(2, a.s_l);
+            ub = PS(3, a.s_u); ubr = PS(3, a.s_r); ubrr = PS(3, a.s_rr); ubl = PS(3, a.s_l); ubll = PS(3, a.s_ll); ubz = PS(3, a.s_z);
+            vb = PS(4, a.s_u); vbr = PS(4, a.s_r); vbrr = PS(4, a.s_rr); vbl = PS(4, a.s_l); vbll = PS(4, a.s_ll); vbz = PS(4, a.s_z);
+        }
         const double S = sqrt((ubz * ubz) + (vbz * vbz));
         const double l = 1.0 / ((1.0 / (0.4 * a.z[k])) + (1.0 / 80.0));
         const double Kv = (l * l) * S;
@@ -840,6 +875,12 @@ void launch_zinv(sx_handle *h, bool full) {
 void launch_rl_inverse(sx_handle *h, bool full) {
     const int *mask = full ? h->d_mask_full : h->d_mask_eq;
     h->last_mask_full = full;
+    h->node_active = (!full && h->node_mode);
+    if (h->node_active) {            // sx_advance on uniform rings: node-space transforms + ring-wise inner rings only
+        launch_node_fft(h);
+        launch_rl_inverse_fft(h, mask, h->R_in);
+        return;
+    }
     if (fft_path_ok(h)) { launch_rl_inverse_fft(h, mask); return; }
     const int id = timer_id(h, "k_rl_inverse");
     timer_begin(h, id);
@@ -871,6 +912,7 @@ static PhysArgs phys_args(sx_handle *h, int t) {
     a.s_z = h->slot[5]; a.s_zz = h->slot[6];
     a.ts = h->ts;
     for (int i = 0; i < SX_NPARAMS; i++) a.par[i] = h->par[i];
+    a.col0 = 0; a.col1 = h->Nh; a.G = nullptr; a.phi = nullptr; a.NG = 0; a.L = 1; a.nrings = h->nrings;
     return a;
 }
 
@@ -880,12 +922,27 @@ void launch_physics(sx_handle *h, int t) {
     if (h->eq != SX_EQ_NONE && t == 1) h->rot = 0;
     PhysArgs a = phys_args(h, t);
     if (h->eq == SX_EQ_ONEWAY_SW_HRBL && (h->nz == 64 || h->nz == 32)) {
-        const int id = timer_id(h, "k_phys_hrbl");
-        timer_begin(h, id);
-        if (h->nz == 64) hipLaunchKernelGGL(k_phys_hrbl_mfma<64>, grid1(h->Nh, 16), dim3(1024), 0, h->stream, a);
-        else hipLaunchKernelGGL(k_phys_hrbl_mfma<32>, grid1(h->Nh, 16), dim3(512), 0, h->stream, a);
-        HIPCHK(hipGetLastError());
-        timer_end(h);
+        // rings [0, R_in): ring-wise physical slots; rings [R_in, nrings): node-space transforms (node_mode only)
+        const int64_t split = (h->node_mode && h->node_active) ? (int64_t)h->R_in * h->uniform_L : h->Nh;
+        a.G = h->d_G; a.phi = h->d_phi; a.NG = h->NG; a.L = h->uniform_L; a.nrings = h->nrings;
+        if (split > 0) {
+            const int id = timer_id(h, split < h->Nh ? "k_phys_hrbl_inner" : "k_phys_hrbl");
+            timer_begin(h, id);
+            a.col0 = 0; a.col1 = split;
+            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, false>), grid1(split, 16), dim3(1024), 0, h->stream, a);
+            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, false>), grid1(split, 16), dim3(512), 0, h->stream, a);
+            HIPCHK(hipGetLastError());
+            timer_end(h);
+        }
+        if (split < h->Nh) {
+            const int id = timer_id(h, "k_phys_hrbl");
+            timer_begin(h, id);
+            a.col0 = split; a.col1 = h->Nh;
+            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, true>), grid1(h->Nh - split, 16), dim3(1024), 0, h->stream, a);
+            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, true>), grid1(h->Nh - split, 16), dim3(512), 0, h->stream, a);
+            HIPCHK(hipGetLastError());
+            timer_end(h);
+        }
     } else if (h->eq == SX_EQ_ONEWAY_SW_HRBL) {
         const int id = timer_id(h, "k_phys_hrbl");
         timer_begin(h, id);
