@@ -685,12 +685,14 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 // combines the node-space transforms G of the ring's 4 spline nodes with the basis weights phi, phi', phi'' itself
 // (value / d/dr / d2/dr2 from the value transform; d/dlambda, d2/dlambda2, d/dz from their own transforms), so the
 // 22 physical planes of these rings are never written to or read from HBM.
-template <int NZ, bool NODE>
-__global__ void __launch_bounds__(16 * NZ) k_phys_hrbl_mfma(PhysArgs a) {
-    constexpr int CPB = 16, CS = NZ + 2;           // columns per block, column stride in LDS
-    __shared__ double X[3][CPB * CS];              // div, Kv*ubz, Kv*vbz   -> inputs
-    __shared__ double Y[3][CPB * CS];              // wb,  d/dz(...), d/dz(...) -> outputs
-    __shared__ double s1[2][CPB];                  // ub, vb at level 1 ("10 m")
+// CPB columns per workgroup (<= 16, the MFMA tile width): 8 gives two resident workgroups per CU, so one workgroup's
+// load phase overlaps the other's MFMA / store phase (the unused tile columns cost nothing that matters).
+template <int NZ, bool NODE, int CPB>
+__global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgs a) {
+    constexpr int CS = NZ + 2;                     // column stride in LDS
+    __shared__ double X[3][16 * CS];               // div, Kv*ubz, Kv*vbz   -> inputs (columns >= CPB unused)
+    __shared__ double Y[3][16 * CS];               // wb,  d/dz(...), d/dz(...) -> outputs
+    __shared__ double s1[2][16];                   // ub, vb at level 1 ("10 m")
     const int k = threadIdx.x % NZ, cl = threadIdx.x / NZ;
     const int64_t col = a.col0 + (int64_t)blockIdx.x * CPB + cl;
     const bool live = col < a.col1;
@@ -700,8 +702,13 @@ __global__ void __launch_bounds__(16 * NZ) k_phys_hrbl_mfma(PhysArgs a) {
     double r = 1.0, h = 0, hr = 0, hl = 0, ug = 0, ugr = 0, ugl = 0, vg = 0, vgr = 0, vgl = 0;
     double ub = 0, ubr = 0, ubrr = 0, ubl = 0, ubll = 0, ubz = 0, vb = 0, vbr = 0, vbrr = 0, vbl = 0, vbll = 0, vbz = 0;
     double xd = 0.0, xu = 0.0, xv = 0.0;
+    // 22 divisions by r / r^2 per point would make this kernel VALU-bound (an f64 division is ~25 instructions): the
+    // reciprocal is formed once per thread and multiplied (differs from the reference's a / r by <= 1.5 ulp)
+    double ri = 1.0, ri2 = 1.0;
     if (live) {
         r = a.r[col];
+        ri = 1.0 / r;
+        ri2 = ri * ri;
         if (NODE) {
             const int ring = (int)(col / a.L);
             const int lam = (int)(col - (int64_t)ring * a.L);
@@ -737,7 +744,7 @@ __global__ void __launch_bounds__(16 * NZ) k_phys_hrbl_mfma(PhysArgs a) {
         const double S = sqrt((ubz * ubz) + (vbz * vbz));
         const double l = 1.0 / ((1.0 / (0.4 * a.z[k])) + (1.0 / 80.0));
         const double Kv = (l * l) * S;
-        xd = -((ub / r) + ubr + (vbl / r));
+        xd = -((ub * ri) + ubr + (vbl * ri));
         xu = Kv * ubz;
         xv = Kv * vbz;
         if (k == 1) { s1[0][cl] = ub; s1[1][cl] = vb; }
@@ -762,8 +769,9 @@ __global__ void __launch_bounds__(16 * NZ) k_phys_hrbl_mfma(PhysArgs a) {
     {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         constexpr int RT = NZ / 16;                 // row tiles per operand
-        if (wave < 3 * RT) {
-            const int op = wave / RT, rt = wave % RT;
+        constexpr int NW = CPB * NZ / 64;           // waves in the workgroup
+        for (int job = wave; job < 3 * RT; job += NW) {
+            const int op = job / RT, rt = job % RT;
             const double *MT = (op == 0) ? a.MintT : a.MdzT;      // MT[j][k] = M[k][j]
             const double *xb = X[op] + (lane & 15) * CS + (lane >> 4);
             const double *ma = MT + (int64_t)(lane >> 4) * NZ + rt * 16 + (lane & 15);
@@ -779,13 +787,13 @@ __global__ void __launch_bounds__(16 * NZ) k_phys_hrbl_mfma(PhysArgs a) {
     if (!live) return;
     const double wb = Y[0][cl * CS + k], vdu = Y[1][cl * CS + k], vdv = Y[2][cl * CS + k];
     a.physw[((int64_t)a.s_u * a.V + 5) * a.N + p] = wb;
-    const double e0 = ((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)));
-    const double e1 = ((-vg * ugl / r) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg / r)));
-    const double e2 = ((-vg * vgl / r) + (-ug * vgr)) + (-g * (hl / r)) + (-ug * (f + (vg / r)));
-    const double e3 = ((-vb * ubl / r) + (-ub * ubr) + (-wb * ubz)) + (-g * hr) + (vb * (f + (vb / r))) + vdu +
-                      (Kh * ((ubr / r) + ubrr - (ub / (r * r)) + (ubll / (r * r)) - (2.0 * vbl / (r * r))));
-    const double e4 = ((-vb * vbl / r) + (-ub * vbr) + (-wb * vbz)) + (-g * (hl / r)) + (-ub * (f + (vb / r))) + vdv +
-                      (Kh * ((vbr / r) + vbrr - (vb / (r * r)) + (vbll / (r * r)) + (2.0 * ubl / (r * r))));
+    const double e0 = ((-vg * hl * ri) + (-ug * hr)) + (-(Hfree + h) * ((ug * ri) + ugr + (vgl * ri)));
+    const double e1 = ((-vg * ugl * ri) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg * ri)));
+    const double e2 = ((-vg * vgl * ri) + (-ug * vgr)) + (-g * (hl * ri)) + (-ug * (f + (vg * ri)));
+    const double e3 = ((-vb * ubl * ri) + (-ub * ubr) + (-wb * ubz)) + (-g * hr) + (vb * (f + (vb * ri))) + vdu +
+                      (Kh * ((ubr * ri) + ubrr - (ub * ri2) + (ubll * ri2) - (2.0 * vbl * ri2)));
+    const double e4 = ((-vb * vbl * ri) + (-ub * vbr) + (-wb * vbz)) + (-g * (hl * ri)) + (-ub * (f + (vb * ri))) + vdv +
+                      (Kh * ((vbr * ri) + vbrr - (vb * ri2) + (vbll * ri2) + (2.0 * ubl * ri2)));
     ab_step(a, 0, p, h, e0);
     ab_step(a, 1, p, ug, e1);
     ab_step(a, 2, p, vg, e2);
@@ -918,6 +926,8 @@ static PhysArgs phys_args(sx_handle *h, int t) {
 
 // History rotation replaces the copies of explicit_timestep: after step t the buffer written as expdot_n becomes
 // expdot_nm1 and the previous nm1 becomes nm2. rot decreases by one (mod 3) per step.
+constexpr int PCPB = 16;      // columns per workgroup of the MFMA HRBL kernel (8: two resident workgroups, measured slower)
+
 void launch_physics(sx_handle *h, int t) {
     if (h->eq != SX_EQ_NONE && t == 1) h->rot = 0;
     PhysArgs a = phys_args(h, t);
@@ -929,8 +939,8 @@ void launch_physics(sx_handle *h, int t) {
             const int id = timer_id(h, split < h->Nh ? "k_phys_hrbl_inner" : "k_phys_hrbl");
             timer_begin(h, id);
             a.col0 = 0; a.col1 = split;
-            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, false>), grid1(split, 16), dim3(1024), 0, h->stream, a);
-            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, false>), grid1(split, 16), dim3(512), 0, h->stream, a);
+            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, false, PCPB>), grid1(split, PCPB), dim3(PCPB * 64), 0, h->stream, a);
+            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, false, PCPB>), grid1(split, PCPB), dim3(PCPB * 32), 0, h->stream, a);
             HIPCHK(hipGetLastError());
             timer_end(h);
         }
@@ -938,8 +948,8 @@ void launch_physics(sx_handle *h, int t) {
             const int id = timer_id(h, "k_phys_hrbl");
             timer_begin(h, id);
             a.col0 = split; a.col1 = h->Nh;
-            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, true>), grid1(h->Nh - split, 16), dim3(1024), 0, h->stream, a);
-            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, true>), grid1(h->Nh - split, 16), dim3(512), 0, h->stream, a);
+            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, true, PCPB>), grid1(h->Nh - split, PCPB), dim3(PCPB * 64), 0, h->stream, a);
+            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, true, PCPB>), grid1(h->Nh - split, PCPB), dim3(PCPB * 32), 0, h->stream, a);
             HIPCHK(hipGetLastError());
             timer_end(h);
         }
