@@ -705,7 +705,15 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgs a) {
     // 22 divisions by r / r^2 per point would make this kernel VALU-bound (an f64 division is ~25 instructions): the
     // reciprocal is formed once per thread and multiplied (differs from the reference's a / r by <= 1.5 ulp)
     double ri = 1.0, ri2 = 1.0;
+    // tendency history of the five prognostic variables: fetched now so that its HBM latency overlaps the load phase
+    // (with one 1024-thread workgroup per CU nothing else would hide it at the end of the kernel)
+    double e1h[5] = {0, 0, 0, 0, 0}, e2h[5] = {0, 0, 0, 0, 0};
     if (live) {
+#pragma unroll
+        for (int v = 0; v < 5; v++) {
+            if (a.t >= 2) e1h[v] = a.E1[(int64_t)v * a.N + p];
+            if (a.t >= 3) e2h[v] = a.E2[(int64_t)v * a.N + p];
+        }
         r = a.r[col];
         ri = 1.0 / r;
         ri2 = ri * ri;
@@ -794,11 +802,17 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgs a) {
                       (Kh * ((ubr * ri) + ubrr - (ub * ri2) + (ubll * ri2) - (2.0 * vbl * ri2)));
     const double e4 = ((-vb * vbl * ri) + (-ub * vbr) + (-wb * vbz)) + (-g * (hl * ri)) + (-ub * (f + (vb * ri))) + vdv +
                       (Kh * ((vbr * ri) + vbrr - (vb * ri2) + (vbll * ri2) + (2.0 * ubl * ri2)));
-    ab_step(a, 0, p, h, e0);
-    ab_step(a, 1, p, ug, e1);
-    ab_step(a, 2, p, vg, e2);
-    ab_step(a, 3, p, ub, e3);
-    ab_step(a, 4, p, vb, e4);
+    const double uu[5] = {h, ug, vg, ub, vb}, ee[5] = {e0, e1, e2, e3, e4};
+#pragma unroll
+    for (int v = 0; v < 5; v++) {          // explicit_timestep (src/semiimplicit.jl:672-698) with the prefetched history
+        const int64_t o = (int64_t)v * a.N + p;
+        a.En[o] = ee[v];
+        double un;
+        if (a.t == 1) un = uu[v] + (a.ts * ee[v]);
+        else if (a.t == 2) un = uu[v] + (0.5 * a.ts) * ((3.0 * ee[v]) - e1h[v]);
+        else un = uu[v] + ((a.ts / 12.0) * ((23.0 * ee[v]) - (16.0 * e1h[v]) + (5.0 * e2h[v])));
+        a.np1[o] = un;
+    }
     diag_step(a, 5, p, wb);
     for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
 }

@@ -62,8 +62,21 @@ def test_rlz_hrbl_fft_rings(ring_L, zDim, cells):
 
 @pytest.mark.parametrize("zDim", [64, 32])
 def test_rlz_hrbl_mfma_column_operators(zDim):
-    """zDim 64 / 32 take the f64-MFMA column-operator kernel (16 columns per workgroup, ragged last block)."""
+    """zDim 64 / 32 take the f64-MFMA column-operator kernel (16 columns per workgroup, ragged last block) and, on
+    uniform rings, the node-space ("radial last") inverse: rings 1..6 ring-wise, rings 7..9 from node transforms."""
     assert _run(cases.rlz_hrbl(num_cells=3, zDim=zDim, ring_L=16), 3) < TOL
+
+
+def test_node_space_inverse_equals_ring_wise_inverse(monkeypatch):
+    """Same model with the node-space path switched off (SX_NODE_MODE=0): fields agree to rounding."""
+    case = cases.rlz_hrbl(num_cells=8, zDim=32, ring_L=32)
+    a = cases.HipModel(case)
+    monkeypatch.setenv("SX_NODE_MODE", "0")
+    b = cases.HipModel(case)
+    for _ in range(4):
+        a.step()
+        b.step()
+    assert cases.rel_err_per_var(a.physical(), b.physical()) < 1e-11
 
 
 def test_rl_slab_fft_rings():
@@ -74,7 +87,8 @@ def test_rlz_advection():
     assert _run(cases.rlz_advection(), 6) < TOL
 
 
-@pytest.mark.parametrize("maker,kw,ntiles", [(cases.kat_r, {}, 2), (cases.kat_r, {}, 3), (cases.rl_slab, {"num_cells": 9}, 2),
+@pytest.mark.parametrize("maker,kw,ntiles", [(cases.rlz_hrbl, {"num_cells": 9, "zDim": 32, "ring_L": 16}, 3),
+                                             (cases.kat_r, {}, 2), (cases.kat_r, {}, 3), (cases.rl_slab, {"num_cells": 9}, 2),
                                              (cases.rl_slab, {"num_cells": 10}, 3), (cases.rlz_hrbl, {"num_cells": 7}, 2),
                                              (cases.rz_semiimplicit, {"num_cells": 9}, 3)])
 @pytest.mark.parametrize("exchange", ["gather", "a2a"])
