@@ -183,7 +183,7 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_%s.json" % args.workload)
         if world == 1 and os.path.exists(tfile):
-            traffic = next((v["hbm_bytes"] for k, v in json.load(open(tfile)).items() if k.startswith(name)), None)
+            traffic = json.load(open(tfile)).get(name, {}).get("hbm_bytes")
         out = {
             "metric": "model steps/sec, RLZ 512x256x64 shallow-water",
             "value": args.steps / elapsed,

@@ -10,12 +10,24 @@ import json
 import sys
 
 
+def timer_name(kernel):
+    """rocprof kernel name -> the timer name bench.py reports (template variants that bench.py times separately keep
+    separate rows: the node-space and ring-wise FFT inverses, the node-space and ring-wise HRBL kernels)."""
+    k = kernel.split("(")[0].replace("void ", "").replace("sx::", "")
+    base, _, targs = k.partition("<")
+    targs = targs.rstrip(">").replace(" ", "").split(",") if targs else []
+    if base == "k_rl_inverse_fft":
+        return "k_node_fft" if targs[-1] in ("true", "1") else "k_rl_inverse"
+    if base == "k_phys_hrbl_mfma":           # <NZ, NODE, CPB>
+        return "k_phys_hrbl" if targs[1] in ("true", "1") else "k_phys_hrbl_inner"
+    return {"k_fl_forward_fft": "k_fl_forward", "k_colmat": "k_zinv", "k_solve_banded": "k_solve"}.get(base, base)
+
+
 def load(path, name):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sx::", "")
-            k = k.split("<")[0]
+            k = timer_name(r["Kernel_Name"])
             agg[k].append(float(r["Counter_Value"]))
     return agg
 
@@ -30,6 +42,8 @@ def main():
         rd = 2.0 * 1024.0 * sum(f.get(k, [0])) / max(len(f.get(k, [0])), 1)
         wr = 1024.0 * sum(w.get(k, [0])) / max(len(w.get(k, [0])), 1)
         res[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr, "launches_sampled": len(f.get(k, []))}
+    if "k_phys_hrbl" not in res and "k_phys_hrbl_inner" in res:      # ring-wise build: one HRBL launch over all rings
+        res["k_phys_hrbl"] = res.pop("k_phys_hrbl_inner")
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
         print("%-22s read %8.1f MB  write %8.1f MB" % (k, v["read_bytes"] / 1e6, v["write_bytes"] / 1e6))

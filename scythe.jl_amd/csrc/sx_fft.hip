@@ -122,14 +122,14 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw
 }
 
 // ------------------------------------------------------------------------------------------------ inverse
-template <int LOGL, int COPYOUT>
+template <int LOGL, int COPYOUT, bool NODE>
 __global__ void __launch_bounds__(512, 4)
 k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const double *__restrict__ phi,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,
                  int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
-                 int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz, int node_mode) {
-    // node_mode: the "rings" are radial NODES (uniform ring tables only): one Az row per unit, no radial combination;
+                 int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz) {
+    // NODE: the "rings" are radial NODES (uniform ring tables only): one Az row per unit, no radial combination;
     // the output is the node-space array G that the equation-set kernel combines with the basis weights itself.
     constexpr int L = 1 << LOGL, T = L / 4;
     extern __shared__ double2 smf[];
@@ -145,7 +145,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const
     int par = 0;
     Twiddles<LOGL> tw;
     tw.template init<+1>(twg, t);
-    const int j0 = node_mode ? ring : ring / MUBAR;
+    const int j0 = NODE ? ring : ring / MUBAR;
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int mask = slotmask[v];
@@ -170,7 +170,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const
             const double *a0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + za)) * K2;
             const double *b0 = a0 + (hasb ? K2 : 0);
 #pragma unroll 2
-            for (int r = 0; r < (node_mode ? 1 : 4); r++) {
+            for (int r = 0; r < (NODE ? 1 : 4); r++) {
                 const double fr = pf[r];
                 if (in1) {
                     const double2 x = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * k1);
@@ -316,9 +316,10 @@ template <int LOGL>
 static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, const double *az, int64_t azrow) {
     const int L = 1 << LOGL;
     dim3 g((h->nz + FZC - 1) / FZC, h->V, tg.n_units);
-    hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az, tg.out, tg.phi, tg.kmax,
+    auto kern = tg.node_mode ? k_rl_inverse_fft<LOGL, 1, true> : k_rl_inverse_fft<LOGL, 1, false>;
+    hipLaunchKernelGGL(kern, g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az, tg.out, tg.phi, tg.kmax,
                        tg.pstart, h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],
-                       h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6], tg.node_mode);
+                       h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);
 }
 
 static void launch_inv_any(sx_handle *h, const int *d_mask, const InvTarget &tg) {
