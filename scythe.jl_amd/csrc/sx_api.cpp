@@ -490,6 +490,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
             h->node_mode = 1;
             h->R_in = 0;
             while (h->R_in < h->nrings && h->hkmax[h->R_in] < h->kDim) h->R_in++;
+            h->R_in = std::min(h->nrings, (h->R_in + MUBAR - 1) / MUBAR * MUBAR);   // whole cells on either side
             for (int i = h->R_in; i < h->nrings; i++)
                 if (h->hkmax[i] != h->kDim) h->node_mode = 0;          // truncation must be ring-independent beyond R_in
             if (h->R_in == h->nrings) h->node_mode = 0;                // no ring on the node-space path

@@ -817,6 +817,150 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgs a) {
     for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
 }
 
+// Cell-wise node-space variant ("radial last", uniform rings): one workgroup = LAM azimuths x NZ levels of ONE radial
+// cell, i.e. the 3 rings that share the same 4 spline nodes.  Each thread loads the 14 node transforms of its
+// (lambda, z) at the 4 nodes once (56 values, kept in registers) and evaluates all 3 rings from them, so a node value
+// enters the CU once instead of three times (the ring-wise grouping was bound by L1 fill rate, not by HBM).
+// The column operators of the 3 x LAM columns run as one f64-MFMA batch; the fields are re-formed from the registers
+// after it, ring by ring, for the tendencies.
+template <int NZ, int LAM>
+__global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgs a, int cell0) {
+    constexpr int CS = NZ + 2;
+    constexpr int NCOL = 3 * LAM, NT = (NCOL + 15) / 16;
+    __shared__ double X[3][NT * 16 * CS];
+    __shared__ double Y[3][NT * 16 * CS];
+    __shared__ double s1[2][NCOL];
+    const int k = threadIdx.x % NZ, ll = threadIdx.x / NZ;
+    const int nlb = a.L / LAM;
+    const int cell = cell0 + blockIdx.x / nlb;
+    const int lam = (blockIdx.x % nlb) * LAM + ll;
+    const double *par = a.par;
+    const double g = par[SX_P_G], Kh = par[SX_P_KH], Hfree = par[SX_P_HFREE], f = par[SX_P_F];
+    const int64_t gp = ((int64_t)cell * a.L + lam) * NZ + k;
+    const int64_t gs = (int64_t)a.L * NZ;
+    // node transforms: [transform][node]
+    double qh[4], qhl[4], qug[4], qugl[4], qvg[4], qvgl[4];
+    double qub[4], qubl[4], qubll[4], qubz[4], qvb[4], qvbl[4], qvbll[4], qvbz[4];
+#define GLOAD(dst, v, s)                                                                           \
+    {                                                                                              \
+        const double *gq = a.G + ((int64_t)(s) * a.V + (v)) * a.NG + gp;                           \
+        dst[0] = gq[0]; dst[1] = gq[gs]; dst[2] = gq[2 * gs]; dst[3] = gq[3 * gs];                 \
+    }
+    GLOAD(qub, 3, a.s_u) GLOAD(qubz, 3, a.s_z) GLOAD(qvbz, 4, a.s_z) GLOAD(qvbl, 4, a.s_l) GLOAD(qvb, 4, a.s_u)
+    GLOAD(qh, 0, a.s_u) GLOAD(qhl, 0, a.s_l) GLOAD(qug, 1, a.s_u) GLOAD(qugl, 1, a.s_l) GLOAD(qvg, 2, a.s_u) GLOAD(qvgl, 2, a.s_l)
+    GLOAD(qubl, 3, a.s_l) GLOAD(qubll, 3, a.s_ll) GLOAD(qvbll, 4, a.s_ll)
+#undef GLOAD
+    // tendency history of ring mu = 0, fetched now (latency hidden behind the operator phase); the next ring's is
+    // fetched while the current ring is finished
+    double e1h[MUBAR][5], e2h[MUBAR][5];
+    const int64_t pc = ((int64_t)(cell * MUBAR) * a.L + lam) * NZ + k;      // ring mu = 0; + mu * L * NZ for the others
+#define HIST(mu)                                                                                   \
+    _Pragma("unroll") for (int v = 0; v < 5; v++) {                                                \
+        e1h[mu][v] = (a.t >= 2) ? a.E1[(int64_t)v * a.N + pc + (mu) * gs] : 0.0;                   \
+        e2h[mu][v] = (a.t >= 3) ? a.E2[(int64_t)v * a.N + pc + (mu) * gs] : 0.0;                   \
+    }
+    HIST(0)
+#define DOT(w, q) ((w)[0] * q[0] + (w)[1] * q[1] + (w)[2] * q[2] + (w)[3] * q[3])
+    const double lmix = 1.0 / ((1.0 / (0.4 * a.z[k])) + (1.0 / 80.0));
+#pragma unroll
+    for (int mu = 0; mu < MUBAR; mu++) {
+        const int ring = cell * MUBAR + mu;
+        const double *w0 = a.phi + (int64_t)ring * 4, *w1 = w0 + (int64_t)a.nrings * 4;
+        const double ri = 1.0 / a.r[(int64_t)ring * a.L];
+        const double ub = DOT(w0, qub), ubr = DOT(w1, qub), vbl = DOT(w0, qvbl), ubz = DOT(w0, qubz), vbz = DOT(w0, qvbz);
+        const double S = sqrt((ubz * ubz) + (vbz * vbz));
+        const double Kv = (lmix * lmix) * S;
+        const int c = mu * LAM + ll;
+        X[0][c * CS + k] = -((ub * ri) + ubr + (vbl * ri));
+        X[1][c * CS + k] = Kv * ubz;
+        X[2][c * CS + k] = Kv * vbz;
+        if (k == 1) { s1[0][c] = ub; s1[1][c] = DOT(w0, qvb); }
+    }
+    __syncthreads();
+    HIST(1)
+    if (k < MUBAR) {       // surface drag replaces the level-0 flux (src/shallowWaterModels.jl:463-482); lane k takes ring k
+        const double Um = par[SX_P_UM], Vm = par[SX_P_VM];
+        {
+            const int mu = k;
+            const int64_t col = (int64_t)(cell * MUBAR + mu) * a.L + lam;
+            const int c = mu * LAM + ll;
+            const double cs = a.cosl[col], sn = a.sinl[col];
+            const double sfcu = (Um * cs) + (Vm * sn), sfcv = (Vm * cs) - (Um * sn);
+            const double u10 = s1[0][c] + sfcu, v10 = s1[1][c] + sfcv;
+            const double U10 = sqrt(u10 * u10 + v10 * v10);
+            double Cd = par[SX_P_CD];
+            if (U10 < 5.2) Cd = 1.0e-3;
+            else if (U10 < 33.6) Cd = 4.4e-4 * sqrt(U10);
+            X[1][c * CS] = Cd * U10 * u10;
+            X[2][c * CS] = Cd * U10 * v10;
+        }
+    }
+    __syncthreads();
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        constexpr int RT = NZ / 16, NW = LAM * NZ / 64;
+        for (int unit = wave; unit < RT * NT; unit += NW) {
+            const int rt = unit % RT, nt = unit / RT;
+            const int64_t ao = (int64_t)(lane >> 4) * NZ + rt * 16 + (lane & 15);      // MT[j][k] = M[k][j]
+            double ai[NZ / 4], ad[NZ / 4];
+#pragma unroll
+            for (int ks = 0; ks < NZ / 4; ks++) { ai[ks] = a.MintT[ao + (int64_t)ks * 4 * NZ]; ad[ks] = a.MdzT[ao + (int64_t)ks * 4 * NZ]; }
+            const int xo = (nt * 16 + (lane & 15)) * CS + (lane >> 4);
+            mfma_d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, c2 = c0;
+#pragma unroll
+            for (int ks = 0; ks < NZ / 4; ks++) {
+                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[ks], X[0][xo + ks * 4], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], X[1][xo + ks * 4], c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], X[2][xo + ks * 4], c2, 0, 0, 0);
+            }
+            const int yo = (nt * 16 + (lane & 15)) * CS + rt * 16 + (lane >> 4);
+            Y[0][yo] = c0[0]; Y[0][yo + 4] = c0[1]; Y[0][yo + 8] = c0[2]; Y[0][yo + 12] = c0[3];
+            Y[1][yo] = c1[0]; Y[1][yo + 4] = c1[1]; Y[1][yo + 8] = c1[2]; Y[1][yo + 12] = c1[3];
+            Y[2][yo] = c2[0]; Y[2][yo + 4] = c2[1]; Y[2][yo + 8] = c2[2]; Y[2][yo + 12] = c2[3];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mu = 0; mu < MUBAR; mu++) {
+        const int ring = cell * MUBAR + mu;
+        const int64_t p = pc + mu * gs;
+        if (mu == 0) { HIST(2) }
+        const double *w0 = a.phi + (int64_t)ring * 4, *w1 = w0 + (int64_t)a.nrings * 4, *w2 = w1 + (int64_t)a.nrings * 4;
+        const double ri = 1.0 / a.r[(int64_t)ring * a.L], ri2 = ri * ri;
+        const double h = DOT(w0, qh), hr = DOT(w1, qh), hl = DOT(w0, qhl);
+        const double ug = DOT(w0, qug), ugr = DOT(w1, qug), ugl = DOT(w0, qugl);
+        const double vg = DOT(w0, qvg), vgr = DOT(w1, qvg), vgl = DOT(w0, qvgl);
+        const double ub = DOT(w0, qub), ubr = DOT(w1, qub), ubrr = DOT(w2, qub);
+        const double ubl = DOT(w0, qubl), ubll = DOT(w0, qubll), ubz = DOT(w0, qubz);
+        const double vb = DOT(w0, qvb), vbr = DOT(w1, qvb), vbrr = DOT(w2, qvb);
+        const double vbl = DOT(w0, qvbl), vbll = DOT(w0, qvbll), vbz = DOT(w0, qvbz);
+        const int c = mu * LAM + ll;
+        const double wb = Y[0][c * CS + k], vdu = Y[1][c * CS + k], vdv = Y[2][c * CS + k];
+        a.physw[((int64_t)a.s_u * a.V + 5) * a.N + p] = wb;
+        const double e0 = ((-vg * hl * ri) + (-ug * hr)) + (-(Hfree + h) * ((ug * ri) + ugr + (vgl * ri)));
+        const double e1 = ((-vg * ugl * ri) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg * ri)));
+        const double e2 = ((-vg * vgl * ri) + (-ug * vgr)) + (-g * (hl * ri)) + (-ug * (f + (vg * ri)));
+        const double e3 = ((-vb * ubl * ri) + (-ub * ubr) + (-wb * ubz)) + (-g * hr) + (vb * (f + (vb * ri))) + vdu +
+                          (Kh * ((ubr * ri) + ubrr - (ub * ri2) + (ubll * ri2) - (2.0 * vbl * ri2)));
+        const double e4 = ((-vb * vbl * ri) + (-ub * vbr) + (-wb * vbz)) + (-g * (hl * ri)) + (-ub * (f + (vb * ri))) + vdv +
+                          (Kh * ((vbr * ri) + vbrr - (vb * ri2) + (vbll * ri2) + (2.0 * ubl * ri2)));
+        const double uu[5] = {h, ug, vg, ub, vb}, ee[5] = {e0, e1, e2, e3, e4};
+#pragma unroll
+        for (int v = 0; v < 5; v++) {          // explicit_timestep (src/semiimplicit.jl:672-698)
+            const int64_t o = (int64_t)v * a.N + p;
+            a.En[o] = ee[v];
+            double un;
+            if (a.t == 1) un = uu[v] + (a.ts * ee[v]);
+            else if (a.t == 2) un = uu[v] + (0.5 * a.ts) * ((3.0 * ee[v]) - e1h[mu][v]);
+            else un = uu[v] + ((a.ts / 12.0) * ((23.0 * ee[v]) - (16.0 * e1h[mu][v]) + (5.0 * e2h[mu][v])));
+            a.np1[o] = un;
+        }
+        diag_step(a, 5, p, wb);
+    }
+#undef DOT
+#undef HIST
+}
+
 // semiimplicit_adjustment (src/semiimplicit.jl:521-597), one workgroup per group of columns
 struct SemiArgs {
     double *np1;
@@ -962,8 +1106,14 @@ void launch_physics(sx_handle *h, int t) {
             const int id = timer_id(h, "k_phys_hrbl");
             timer_begin(h, id);
             a.col0 = split; a.col1 = h->Nh;
-            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, true, PCPB>), grid1(h->Nh - split, PCPB), dim3(PCPB * 64), 0, h->stream, a);
-            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, true, PCPB>), grid1(h->Nh - split, PCPB), dim3(PCPB * 32), 0, h->stream, a);
+            const int ncell = (h->nrings - h->R_in) / MUBAR;         // R_in is a multiple of 3 (sx_create)
+            if (h->nz == 64) {
+                constexpr int LAM = 4;
+                hipLaunchKernelGGL((k_phys_hrbl_cell<64, LAM>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 64), 0, h->stream, a, h->R_in / MUBAR);
+            } else {
+                constexpr int LAM = 8;
+                hipLaunchKernelGGL((k_phys_hrbl_cell<32, LAM>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 32), 0, h->stream, a, h->R_in / MUBAR);
+            }
             HIPCHK(hipGetLastError());
             timer_end(h);
         }
