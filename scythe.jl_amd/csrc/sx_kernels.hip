@@ -261,6 +261,93 @@ k_sbz(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
     }
 }
 
+// Sliding-window form of k_sbz for zDim = NZ (multiple of 8): a workgroup walks a run of consecutive radial cells for
+// one (variable, 64 wavenumber blocks) and keeps the partial inner products of the 4 nodes a cell touches in registers,
+// so every Fl value enters the CU once (k_sbz re-reads it for each of its 4 nodes: 4x the L2 -> L1 traffic, which is
+// what bounds it).  Node c is complete once cell c has been added (cells c-3..c); its [NZ][64] tile then goes through
+// LDS into the vertical contraction with CB.  A segment starts 3 cells early to warm up its first nodes.
+// Summation order per node (cells ascending, mish points ascending) is the same as k_sbz's.
+template <int NZ>
+__global__ void __launch_bounds__(512)
+k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__restrict__ phi, const double *__restrict__ wq,
+      const double *__restrict__ CB, int ncells, int V, int Zb, int K2, int64_t C, int cps) {
+    constexpr int ZPT = NZ / 8;
+    __shared__ double As[NZ * 64];
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * 64 + lane;
+    const int v = blockIdx.y;
+    const bool ok = blk < K2;
+    const int ca = blockIdx.z * cps, cb = min(ca + cps, ncells);
+    const int cend = (cb == ncells) ? ncells + 3 : cb;          // the last segment also owns the 3 trailing nodes
+    const int cstart = max(0, ca - 3);
+    const int64_t plane = (int64_t)V * NZ * K2;
+    const double *base = Fl + ((int64_t)v * NZ + g) * K2 + (ok ? blk : 0);
+    double *dst0 = B + (int64_t)v * Zb * K2 + blk;
+    double acc[4][ZPT];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < ZPT; i++) acc[q][i] = 0.0;
+    for (int c4 = cstart & ~3; c4 < cend; c4 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = c4 + u;
+            if (c < cstart || c >= cend) continue;
+            if (c < ncells) {
+#pragma unroll
+                for (int mu = 0; mu < MUBAR; mu++) {
+                    const int ring = c * MUBAR + mu;
+                    const double w = wq[ring];
+                    const double w0 = w * phi[(int64_t)ring * 4], w1 = w * phi[(int64_t)ring * 4 + 1];
+                    const double w2 = w * phi[(int64_t)ring * 4 + 2], w3 = w * phi[(int64_t)ring * 4 + 3];
+                    const double *src = base + (int64_t)ring * plane;
+                    double x[ZPT];
+#pragma unroll
+                    for (int i = 0; i < ZPT; i++) x[i] = src[(int64_t)(8 * i) * K2];
+#pragma unroll
+                    for (int i = 0; i < ZPT; i++) {
+                        acc[u][i] += w0 * x[i];
+                        acc[(u + 1) & 3][i] += w1 * x[i];
+                        acc[(u + 2) & 3][i] += w2 * x[i];
+                        acc[(u + 3) & 3][i] += w3 * x[i];
+                    }
+                }
+            }
+            if (c >= ca) {                      // node c is complete: vertical forward transform and store
+                __syncthreads();                // the previous node's tile has been consumed
+#pragma unroll
+                for (int i = 0; i < ZPT; i++) As[(g + 8 * i) * 64 + lane] = acc[u][i];
+                __syncthreads();
+                double *dst = dst0 + (int64_t)c * C;
+                for (int o0 = g * 4; o0 < Zb; o0 += 32) {
+                    const double *m0 = CB + (int64_t)o0 * NZ;
+                    const double *m1 = CB + (int64_t)min(o0 + 1, Zb - 1) * NZ;
+                    const double *m2 = CB + (int64_t)min(o0 + 2, Zb - 1) * NZ;
+                    const double *m3 = CB + (int64_t)min(o0 + 3, Zb - 1) * NZ;
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 8
+                    for (int i = 0; i < NZ; i++) {
+                        const double xx = As[i * 64 + lane];
+                        a0 += m0[i] * xx;
+                        a1 += m1[i] * xx;
+                        a2 += m2[i] * xx;
+                        a3 += m3[i] * xx;
+                    }
+                    if (ok) {
+                        dst[(int64_t)o0 * K2] = a0;
+                        if (o0 + 1 < Zb) dst[(int64_t)(o0 + 1) * K2] = a1;
+                        if (o0 + 2 < Zb) dst[(int64_t)(o0 + 2) * K2] = a2;
+                        if (o0 + 3 < Zb) dst[(int64_t)(o0 + 3) * K2] = a3;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < ZPT; i++) acc[u][i] = 0.0;      // the slot now belongs to node c + 4
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ B -> A banded SPD solve
 // One lane per right-hand side (column); rows are contiguous across lanes so every load/store is coalesced.
 // a = Gamma^T (L L^T)^-1 Gamma b with L banded (half-bandwidth 3) plus, for PERIODIC, three dense last rows.
@@ -1169,6 +1256,20 @@ void launch_sb(sx_handle *h) {
     if (h->has_z) {        // fused with the vertical forward transform; launch_zf is then a no-op
         const int id = timer_id(h, "k_sbz");
         timer_begin(h, id);
+        if (h->nz == 64 || h->nz == 32 || h->nz == 128) {
+            // cells per workgroup (+3 warm-up cells): about 1.5 workgroups per CU (one round of 2 resident workgroups; 11 at
+            // config 4, measured best of 4..12), never fewer than 6 so that the warm-up stays below half of the reads
+            const int groups = ((h->K2 + 63) / 64) * h->V;
+            const int nseg = std::max(1, 384 / groups);
+            const int cps = std::max(6, (h->ncells + nseg - 1) / nseg);
+            dim3 gw((h->K2 + 63) / 64, h->V, (h->ncells + cps - 1) / cps);
+            auto kern = h->nz == 64 ? k_sbw<64> : h->nz == 32 ? k_sbw<32> : k_sbw<128>;
+            hipLaunchKernelGGL(kern, gw, dim3(512), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->d_CB, h->ncells,
+                               h->V, h->Zb, h->K2, h->C, cps);
+            HIPCHK(hipGetLastError());
+            timer_end(h);
+            return;
+        }
         dim3 g((h->K2 + 63) / 64, h->V, h->nbt);
         hipLaunchKernelGGL(k_sbz, g, dim3(64, 4), sizeof(double) * 64 * h->nz, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq,
                            h->d_CB, h->ncells, h->V, h->nz, h->Zb, h->K2, h->C);
