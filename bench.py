@@ -32,6 +32,8 @@ WORKLOADS = {
     # name: (num_cells, ring_L, zDim)
     "rlz_513x256x64": (171, 256, 64),
     "rlz_small": (24, 64, 16),
+    # SURVEY.md 8(d) config 5 (use with --storage f32): 341 cells -> 1023 rings x 512 x 128
+    "rlz_1023x512x128": (341, 512, 128),
 }
 VARS6 = {"h": 1, "u": 2, "v": 3, "ub": 4, "vb": 5, "wb": 6}
 BCL6 = {"h": "R1T1", "u": "R1T0", "v": "R1T0", "ub": "R1T0", "vb": "R1T0", "wb": "R1T1"}
@@ -107,6 +109,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the multi-rank path on a single GPU (not a performance mode)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
+                    help="f32: derivative slots of `physical` stored as fp32 (config 5; not the headline metric, whose "
+                         "1e-10 parity bar needs fp64 throughout)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=18)
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -135,7 +140,7 @@ def main():
             dist.init_process_group("gloo")
 
     kw, L = grid_kwargs(args.workload)
-    gp = S.GridParameters(ring_uniform_L=L, **kw)
+    gp = S.GridParameters(ring_uniform_L=L, storage=args.storage, **kw)
     mp = S.ModelParameters(ts=TS, equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
                            physical_params=dict(PAR))
     run = S.ModelRun(mp, num_tiles=world, rank=rank, device=torch.device("cuda", local_rank), use_dist=world > 1,
@@ -182,7 +187,7 @@ def main():
         # collected and corrected as profiles/summarize_pmc.py documents); null for other workloads / tilings
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_%s.json" % args.workload)
-        if world == 1 and os.path.exists(tfile):
+        if world == 1 and args.storage == "f64" and os.path.exists(tfile):
             traffic = json.load(open(tfile)).get(name, {}).get("hbm_bytes")
         out = {
             "metric": "model steps/sec, RLZ 512x256x64 shallow-water",
@@ -195,7 +200,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f64" if args.storage == "f64" else "f64 arithmetic and state, fp32-stored derivative planes",
             "data": "synthetic",
             "config": {"workload": "RLZ %dx%dx%d (rings x azimuth x levels), 6 vars, 7 derivative slots, "
                                    "Oneway_ShallowWater_HeightResolvedBL, uniform ring table kmax<=%d, b_zDim %d"

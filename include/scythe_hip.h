@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SX_ABI_VERSION 1
+#define SX_ABI_VERSION 2
 
 /* geometry  (GridParameters.geometry, src/spectralGrid.jl:21, 63-94) */
 enum { SX_GEOM_R = 0, SX_GEOM_RZ = 1, SX_GEOM_RL = 2, SX_GEOM_RLZ = 3 };
@@ -76,6 +76,11 @@ typedef struct sx_grid_desc {
     int32_t tile_cell0;       /* first patch cell of this tile  (= spectralIndexL - 1) */
     int32_t tile_num_cells;   /* cells in this tile */
     int32_t tile_num;         /* informational (GridParameters.tile_num) */
+    int32_t storage_f32;      /* 0: everything fp64 (the reference's arithmetic, `const real = Float64`,
+                                 src/spectralGrid.jl:12).  1: the DERIVATIVE slots of `physical` (and of the node-space
+                                 transforms) are stored as fp32; the value slot, the arithmetic, every spectral array, the
+                                 banded solve and the time-stepping state stay fp64, so no fp32 rounding ever enters the
+                                 model state directly - only the tendencies see it */
 } sx_grid_desc;
 
 /* ModelParameters subset the step needs (src/Scythe.jl:8-21) */
@@ -152,7 +157,8 @@ int sx_tile_transform(sx_handle *h);
 int sx_advance(sx_handle *h, int32_t t);
 /* physical_model only (src/semiimplicit.jl:357-363) on the current tile.physical */
 int sx_physics(sx_handle *h, int32_t t);
-/* checkCFL (src/semiimplicit.jl:737-751): flag = 1 if any NaN in physical[:, v, 1] */
+/* checkCFL (src/semiimplicit.jl:737-751): flag = 1 if any NaN in the model state (scans var_np1, which every
+ * sx_advance / sx_set_physical_values leaves complete; a NaN in physical[:, v, 1] always reaches it) */
 int sx_check_nan(sx_handle *h, int32_t *flag);
 
 /* --- tile <-> patch exchange on the device (src/semiimplicit.jl:320-329, 272-285) ---------------------------------- */

@@ -6,7 +6,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscythe_hip.so")
 
-SX_ABI_VERSION = 1
+SX_ABI_VERSION = 2
 GEOM = {"R": 0, "RZ": 1, "RL": 2, "RLZ": 3}
 BC = {"R0": 0, "R1T0": 1, "R1T1": 2, "R1T2": 3, "R2T10": 4, "R2T20": 5, "R3": 6, "PERIODIC": 7}
 PARAM_ORDER = ["g", "K", "Cd", "Hfree", "Hb", "f", "S1", "c_0", "Kh", "Um", "Vm", "Pxi_bar"]
@@ -22,7 +22,8 @@ class GridDesc(C.Structure):
                 ("bcl", P_I32), ("bcl_k0", P_I32), ("bcr", P_I32),
                 ("zmin", C.c_double), ("zmax", C.c_double), ("zDim", C.c_int32), ("b_zDim", C.c_int32),
                 ("bcb", P_I32), ("bct", P_I32), ("ring_uniform_L", C.c_int32),
-                ("tile_cell0", C.c_int32), ("tile_num_cells", C.c_int32), ("tile_num", C.c_int32)]
+                ("tile_cell0", C.c_int32), ("tile_num_cells", C.c_int32), ("tile_num", C.c_int32),
+                ("storage_f32", C.c_int32)]
 
 
 class ModelDesc(C.Structure):

@@ -28,6 +28,13 @@ static int status() { return g_err_set ? 1 : 0; }
         }                                                                                 \
     } while (0)
 
+// doubles to allocate for `count` elements of the storage type (fp64, or fp32 when storage_f32 is set)
+// for a [D][V][n] plane array whose derivative slots (1..D-1) are fp32 when storage_f32 is set (value slot stays fp64)
+static size_t plane_count(const sx_handle *h, size_t n) {
+    const size_t val = (size_t)h->V * n, der = (size_t)(h->D - 1) * h->V * n;
+    return val + (h->f32 ? (der + 1) / 2 : der);
+}
+
 template <class T>
 static bool dalloc(sx_handle *h, T **p, size_t count, bool zero = true) {
     void *d = nullptr;
@@ -249,6 +256,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->V = g->nvars;
     h->rDim = MUBAR * h->nc; h->b_rDim = h->nc + 3;
     h->uniform_L = h->has_l ? g->ring_uniform_L : 0;
+    h->f32 = g->storage_f32 ? 1 : 0;
     h->cell0 = g->tile_cell0; h->ncells = g->tile_num_cells; h->tile_num = g->tile_num;
     h->nrings = MUBAR * h->ncells; h->nbt = h->ncells + 3;
     for (int i = 0; i < 7; i++) h->slot[i] = DERIV_SLOTS[h->geom][i];
@@ -441,7 +449,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     // ---- state
     const int64_t C = h->C, N = h->N;
     if (!dalloc(h, &h->d_A, (size_t)h->b_rDim * C) || !dalloc(h, &h->d_Bfull, (size_t)h->b_rDim * C) ||
-        !dalloc(h, &h->d_rowoff, (size_t)h->b_rDim) || !dalloc(h, &h->d_aoff, (size_t)h->b_rDim) || !dalloc(h, &h->d_neg1, (size_t)h->b_rDim) || !dalloc(h, &h->d_phys, (size_t)h->D * h->V * N) ||
+        !dalloc(h, &h->d_rowoff, (size_t)h->b_rDim) || !dalloc(h, &h->d_aoff, (size_t)h->b_rDim) || !dalloc(h, &h->d_neg1, (size_t)h->b_rDim) || !dalloc(h, &h->d_phys, plane_count(h, (size_t)N)) ||
         !dalloc(h, &h->d_np1, (size_t)h->V * N) || !dalloc(h, &h->d_flag, 1))
         FAIL();
     for (int i = 0; i < 3; i++) {
@@ -450,8 +458,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     }
     if (!dalloc(h, &h->d_Fl, (size_t)h->nrings * h->V * h->nz * h->K2)) FAIL();
     if (h->has_z) {
-        if (!dalloc(h, &h->d_Az, (size_t)h->nbt * h->V * 3 * h->nz * h->K2) || !dalloc(h, &h->d_Bz, (size_t)h->nbt * h->V * h->nz * h->K2))
-            FAIL();
+        if (!dalloc(h, &h->d_Az, (size_t)h->nbt * h->V * 3 * h->nz * h->K2)) FAIL();
     }
     if (h->ncells == h->nc) {
         h->d_Btile = h->d_Bfull;                      // one-tile patch: the tile's B rows are the patch's B rows
@@ -482,6 +489,8 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         for (int v = 0; v < h->V; v++) {
             h->mask_full_bits += __builtin_popcount(full[v]);
             h->mask_eq_bits += __builtin_popcount(eq[v]);
+            h->mask_full_val += (full[v] & u) ? 1 : 0;
+            h->mask_eq_val += (eq[v] & u) ? 1 : 0;
         }
         if (!upload(h, &h->d_mask_full, full) || !upload(h, &h->d_mask_eq, eq)) FAIL();
         // node-space ("radial last") inverse: uniform power-of-two rings + the MFMA HRBL kernel
@@ -506,10 +515,11 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
                 if (eq[v] & (u | r | rr)) nmask[v] |= u;
                 nmask[v] |= eq[v] & (l | ll | z | zz);
                 h->mask_node_bits += __builtin_popcount(nmask[v]);
+                h->mask_node_val += (nmask[v] & u) ? 1 : 0;
             }
             if (!upload(h, &h->d_nkmax, nkmax) || !upload(h, &h->d_npstart, npstart) || !upload(h, &h->d_nphoff, nphoff) ||
                 !upload(h, &h->d_nphi, nphi) || !upload(h, &h->d_mask_node, nmask) ||
-                !dalloc(h, &h->d_G, (size_t)h->D * h->V * h->NG))
+                !dalloc(h, &h->d_G, plane_count(h, (size_t)h->NG)))
                 FAIL();
         }
         if (h->has_z) {   // vertical-transform job lists: only the (variable, operator) pairs some requested slot needs
@@ -622,7 +632,17 @@ int sx_set_physical_values(sx_handle *h, const double *values) {
 int sx_get_physical(sx_handle *h, double *out) {
     clear_error();
     if (!h || !out) { set_error("null argument"); return 1; }
-    HIPOK(hipMemcpyAsync(out, h->d_phys, sizeof(double) * h->D * h->V * h->N, hipMemcpyDeviceToHost, h->stream));
+    const size_t n = (size_t)h->D * h->V * h->N;
+    if (h->f32) {          // derivative slots are stored as fp32: widen on the host
+        const size_t nv = (size_t)h->V * h->N, nd = n - nv;
+        std::vector<float> tmp(nd);
+        HIPOK(hipMemcpyAsync(out, h->d_phys, sizeof(double) * nv, hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipMemcpyAsync(tmp.data(), h->d_phys + nv, sizeof(float) * nd, hipMemcpyDeviceToHost, h->stream));
+        HIPOK(hipStreamSynchronize(h->stream));
+        for (size_t i = 0; i < nd; i++) out[nv + i] = (double)tmp[i];
+        return status();
+    }
+    HIPOK(hipMemcpyAsync(out, h->d_phys, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
     HIPOK(hipStreamSynchronize(h->stream));
     return status();
 }
@@ -910,27 +930,29 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     clear_error();
     if (!h || !name || !bytes) { set_error("null argument"); return 1; }
     // Algorithmic bytes per launch (fp64), counting each array once (DESIGN.md "Kernels and rooflines").
-    const double w = 8.0, N = (double)h->N, V = h->V, D = h->D;
+    // w = fp64; ws = width of the derivative slots of `physical` / G (4 bytes in the fp32-storage mode; value slots stay fp64)
+    const double w = 8.0, ws = h->f32 ? 4.0 : 8.0, N = (double)h->N, V = h->V;
     const double S_tile = (double)h->nbt * h->C, S_patch = (double)h->b_rDim * h->C;
     const double az = h->has_z ? (double)h->nbt * h->last_zinv_jobs * h->nz * h->K2 : S_tile;
     const double fl = (double)h->nrings * h->V * h->nz * h->K2, bz = (double)h->nbt * h->V * h->nz * h->K2;
     std::string k(name);
     double b = 0;
-    const double planes = h->last_mask_full ? h->mask_full_bits : h->mask_eq_bits;   // (variable, slot) planes produced
-    (void)D;
+    auto planes = [&](int bits, int val) { return w * val + ws * (bits - val); };        // bytes per point of a plane set
+    const double out_planes = h->last_mask_full ? planes(h->mask_full_bits, h->mask_full_val) : planes(h->mask_eq_bits, h->mask_eq_val);
+    const double eq_planes = planes(h->mask_eq_bits, h->mask_eq_val), node_planes = planes(h->mask_node_bits, h->mask_node_val);
     const bool node = h->node_mode && h->node_active;
     const double fin = node ? (double)h->R_in / h->nrings : 1.0;   // fraction of rings on the ring-wise path
-    if (k == "k_rl_inverse") b = w * (N * planes + az) * fin;       // write the requested physical planes, read Az
-    else if (k == "k_node_fft") b = w * ((double)h->NG * h->mask_node_bits + az);
-    else if (k == "k_phys_hrbl_inner") b = w * N * fin * (h->mask_eq_bits + 4.0 * V - 2.0);
+    if (k == "k_rl_inverse") b = (N * out_planes + w * az) * fin;   // write the requested physical planes, read Az
+    else if (k == "k_node_fft") b = (double)h->NG * node_planes + w * az;
+    else if (k == "k_phys_hrbl_inner") b = N * fin * (eq_planes + w * (4.0 * V - 2.0));
     else if (k == "k_phys_hrbl" && node)                            // node transforms (read once) + history + outputs
-        b = w * ((double)h->NG * h->mask_node_bits + N * (1.0 - fin) * (4.0 * V - 2.0));
+        b = (double)h->NG * node_planes + N * (1.0 - fin) * w * (4.0 * V - 2.0);
     else if (k == "k_zinv") b = w * (S_tile + az);
     else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") {
         // read the requested slots, E_nm1, E_nm2; write E_n, var_np1; the SW sets also write the diagnostic w plane and
         // keep no tendency history for it
         const bool sw = (h->eq == SX_EQ_ONEWAY_SW_SLAB || h->eq == SX_EQ_TWOWAY_SW_SLAB || h->eq == SX_EQ_ONEWAY_SW_HRBL);
-        b = w * N * (h->mask_eq_bits + 4.0 * V + (sw ? 1.0 - 3.0 : 0.0));
+        b = N * (eq_planes + w * (4.0 * V + (sw ? 1.0 - 3.0 : 0.0)));
     }
     else if (k == "k_fl_forward") b = w * (N * V + fl);
     else if (k == "k_sb") b = w * (fl + bz);

@@ -122,9 +122,10 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw
 }
 
 // ------------------------------------------------------------------------------------------------ inverse
-template <int LOGL, int COPYOUT, bool NODE>
+// The output planes are `physical` or the node-space array G: value slot fp64, derivative slots ST (Planes, sx_internal.hpp)
+template <int LOGL, int COPYOUT, bool NODE, class ST>
 __global__ void __launch_bounds__(512, 4)
-k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const double *__restrict__ phi,
+k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,
                  int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
@@ -215,22 +216,28 @@ k_rl_inverse_fft(const double *__restrict__ Az, double *__restrict__ phys, const
                 // last pass goes back to LDS, then the whole workgroup writes full 128-byte lines
                 fft_inplace<LOGL, +1, true>(X, tw, t, active);
                 lds_barrier();       // also orders the previous slot's copy-out reads (other set) before that set is restaged
-                double *out = phys + ((int64_t)slot * V + v) * N + p0 * nz + z0;
-                {
-                    // thread -> (level zz, ring point l0 + 32 i): consecutive lanes cover the 16 levels of one point
-                    const int zz = threadIdx.x & (FZC - 1);
-                    const double *src = reinterpret_cast<const double *>(set + (zz >> 1) * (L + SKEW)) + (zz & 1);
+                // thread -> (level zz, ring point l0 + 32 i): consecutive lanes cover the 16 levels of one point
+                const int zz = threadIdx.x & (FZC - 1);
+                const double *src = reinterpret_cast<const double *>(set + (zz >> 1) * (L + SKEW)) + (zz & 1);
+                auto copy_out = [&](auto *out) {
                     if (zz < zc) {
 #pragma unroll 4
                         for (int l = threadIdx.x >> 4; l < L; l += (int)(blockDim.x >> 4)) out[(int64_t)l * nz + zz] = src[2 * l];
                     }
-                }
+                };
+                if (slot == 0) copy_out(phys.val + (int64_t)v * N + p0 * nz + z0);
+                else copy_out(phys.der + ((int64_t)(slot - 1) * V + v) * N + p0 * nz + z0);
             } else {
-                double *out = phys + ((int64_t)slot * V + v) * N + p0 * nz + z0 + za;
+                const int64_t o0 = p0 * nz + z0 + za;
                 fft_inplace<LOGL, +1>(X, tw, t, active, [&](int l, double2 y) {
-                    double *o = out + (int64_t)l * nz;
-                    if (pair_ok && hasb) *reinterpret_cast<double2 *>(o) = y;
-                    else { o[0] = y.x; if (hasb) o[1] = y.y; }
+                    if (slot == 0) {
+                        double *o = phys.val + (int64_t)v * N + o0 + (int64_t)l * nz;
+                        if (pair_ok && hasb) *reinterpret_cast<double2 *>(o) = y;
+                        else { o[0] = y.x; if (hasb) o[1] = y.y; }
+                    } else {
+                        ST *o = phys.der + ((int64_t)(slot - 1) * V + v) * N + o0 + (int64_t)l * nz;
+                        o[0] = (ST)y.x; if (hasb) o[1] = (ST)y.y;
+                    }
                 });
                 wave_sync();      // the region is rewritten by the next slot
             }
@@ -316,10 +323,14 @@ template <int LOGL>
 static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, const double *az, int64_t azrow) {
     const int L = 1 << LOGL;
     dim3 g((h->nz + FZC - 1) / FZC, h->V, tg.n_units);
-    auto kern = tg.node_mode ? k_rl_inverse_fft<LOGL, 1, true> : k_rl_inverse_fft<LOGL, 1, false>;
-    hipLaunchKernelGGL(kern, g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az, tg.out, tg.phi, tg.kmax,
-                       tg.pstart, h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],
-                       h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);
+#define INV_LAUNCH(NODE, ST)                                                                                                         \
+    hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az,                  \
+                       planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart,     \
+                       h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],            \
+                       h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6])
+    if (h->f32) { if (tg.node_mode) INV_LAUNCH(true, float); else INV_LAUNCH(false, float); }
+    else { if (tg.node_mode) INV_LAUNCH(true, double); else INV_LAUNCH(false, double); }
+#undef INV_LAUNCH
 }
 
 static void launch_inv_any(sx_handle *h, const int *d_mask, const InvTarget &tg) {

@@ -45,6 +45,19 @@ bool build_helmholtz(const ChebOps &w, double pxi_bar, double tau, std::vector<d
 void ring_table(int has_l, int uniform_L, int ri /*1-based patch ring*/, int &L, int &kmax, double &off);
 
 // ---- device-side tables handed to the kernels -----------------------------------------------------------------------
+// `physical` [slot][v][N] and the node-space transforms G [slot][v][NG] as the kernels see them: the VALUE slot (slot 0)
+// is always fp64 - it is time-stepping state - while the derivative slots 1..D-1 are ST = double, or float in the
+// fp32-storage mode (sx_grid_desc.storage_f32).  For ST = double `der` = `val` + V * N: the plain [D][V][N] array.
+template <class ST>
+struct Planes {
+    double *val;          // [V][n]
+    ST *der;              // [D-1][V][n]
+};
+template <class ST>
+__host__ __device__ inline Planes<ST> planes_of(double *base, int V, int64_t n) {
+    return Planes<ST>{base, reinterpret_cast<ST *>(base + (int64_t)V * n)};
+}
+
 struct ColJob {
     int64_t in_off, out_off, mat_off;
 };
@@ -92,8 +105,9 @@ struct sx_handle {
     std::vector<int> a2a_cell0, a2a_ncells;
     int *d_a2a_owner = nullptr;
     int64_t *d_a2a_soff = nullptr, *d_a2a_cw = nullptr, *d_a2a_cs = nullptr, *d_a2a_offA = nullptr, *d_a2a_offB = nullptr;
+    int f32 = 0;   // fp32 storage of d_Az, d_phys, d_G, d_Fl (allocated as raw bytes, typed by the launchers)
     double *d_Az = nullptr, *d_phys = nullptr, *d_np1 = nullptr, *d_E[3] = {}, *d_I[3] = {};
-    double *d_Fl = nullptr, *d_Bz = nullptr;
+    double *d_Fl = nullptr;
     double *d_phi = nullptr, *d_wq = nullptr;
     int *d_L = nullptr, *d_kmax = nullptr;
     int64_t *d_pstart = nullptr, *d_twoff = nullptr, *d_phoff = nullptr;
@@ -107,6 +121,7 @@ struct sx_handle {
     int *d_flag = nullptr;
     int *d_mask_full = nullptr, *d_mask_eq = nullptr;   // per-variable bit masks of derivative slots to produce
     int mask_eq_bits = 0, mask_full_bits = 0;            // total number of (variable, slot) planes in each mask
+    int mask_eq_val = 0, mask_full_val = 0, mask_node_val = 0;   // of which value-slot planes (always fp64)
     bool last_mask_full = true;
     // node-space ("radial last") inverse for uniform rings: rings [0, R_in) keep the ring-wise path (their wavenumber
     // truncation depends on the ring), rings [R_in, nrings) are evaluated from node-space transforms inside the equation set

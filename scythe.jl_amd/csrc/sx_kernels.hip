@@ -70,8 +70,9 @@ k_colmat(const double *__restrict__ in, double *__restrict__ out, const double *
 // ------------------------------------------------------------------------------------------------ radial + azimuthal inverse
 // One workgroup per (z-chunk, variable, ring): radial evaluation (4 rows of Az), phase reference, truncated inverse
 // DFT with lambda-derivatives, stores straight into the reference physical layout (z innermost => 128-B lines).
+template <class ST>
 __global__ void __launch_bounds__(256)
-k_rl_inverse(const double *__restrict__ Az, double *__restrict__ phys, const double *__restrict__ phi,
+k_rl_inverse(const double *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
              const int *__restrict__ Lr, const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart,
              const int64_t *__restrict__ twoff, const double2 *__restrict__ tw, const int64_t *__restrict__ phoff,
              const double2 *__restrict__ ph, int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
@@ -138,9 +139,12 @@ k_rl_inverse(const double *__restrict__ Az, double *__restrict__ phys, const dou
                 }
             }
             const int64_t pt = (p0 + l) * nz + z0 + zz;
-            if (need0) phys[((int64_t)slot0 * V + v) * N + pt] = a0;
-            if (needl) phys[((int64_t)s_l * V + v) * N + pt] = a1;
-            if (needll) phys[((int64_t)s_ll * V + v) * N + pt] = a2;
+            if (need0) {
+                if (slot0 == 0) phys.val[(int64_t)v * N + pt] = a0;
+                else phys.der[((int64_t)(slot0 - 1) * V + v) * N + pt] = (ST)a0;
+            }
+            if (needl) phys.der[((int64_t)(s_l - 1) * V + v) * N + pt] = (ST)a1;
+            if (needll) phys.der[((int64_t)(s_ll - 1) * V + v) * N + pt] = (ST)a2;
         }
     }
 }
@@ -567,9 +571,9 @@ __global__ void k_nan_check(const double *__restrict__ x, int64_t n, int *flag) 
 }
 
 // ------------------------------------------------------------------------------------------------ equation sets
-struct PhysArgs {
-    const double *phys;   // [D][V][N]
-    double *physw;        // same array, for the diagnostic w
+template <class ST>
+struct PhysArgsT {
+    Planes<ST> P;         // physical
     double *En;           // expdot_n  [V][N]
     double *E1, *E2;      // expdot_nm1 / nm2 (read)
     double *In;           // impdot_n
@@ -583,17 +587,20 @@ struct PhysArgs {
     double par[SX_NPARAMS];
     // column range of this launch and, for the node-space variant, the node transforms G [slot][v][NG] + basis weights
     int64_t col0, col1;
-    const double *G, *phi;
+    Planes<ST> G;
+    const double *phi;
     int64_t NG;
     int L, nrings;
 };
 
 // A diagnostic variable has expdot == 0 for ever (src/shallowWaterModels.jl:69, 185, 430): explicit_timestep reduces to
 // var_np1 = value, and its (all-zero) tendency history is neither read nor written.
-__device__ __forceinline__ void diag_step(const PhysArgs &a, int v, int64_t p, double u) { a.np1[(int64_t)v * a.N + p] = u; }
+template <class A>
+__device__ __forceinline__ void diag_step(const A &a, int v, int64_t p, double u) { a.np1[(int64_t)v * a.N + p] = u; }
 
 // explicit_timestep (src/semiimplicit.jl:672-698); history arrays are rotated by the host instead of copied
-__device__ __forceinline__ double ab_step(const PhysArgs &a, int v, int64_t p, double u, double en) {
+template <class A>
+__device__ __forceinline__ double ab_step(const A &a, int v, int64_t p, double u, double en) {
     const int64_t o = (int64_t)v * a.N + p;
     a.En[o] = en;
     double un;
@@ -604,50 +611,53 @@ __device__ __forceinline__ double ab_step(const PhysArgs &a, int v, int64_t p, d
     return un;
 }
 
-#define PS(v, s) a.phys[((int64_t)(s) * a.V + (v)) * a.N + p]
+// value of variable v / derivative slot s (>= 1) of variable v at point p
+#define PSV(v) a.P.val[(int64_t)(v) * a.N + p]
+#define PS(v, s) ((double)a.P.der[((int64_t)((s) - 1) * a.V + (v)) * a.N + p])
 
-__global__ void k_phys_pointwise(PhysArgs a) {
+template <class ST>
+__global__ void k_phys_pointwise(PhysArgsT<ST> a) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= a.N) return;
     const double *par = a.par;
     const double r = a.r[p / a.nz];
     switch (a.eq) {
         case SX_EQ_NONE:
-            for (int v = 0; v < a.V; v++) a.np1[(int64_t)v * a.N + p] = PS(v, a.s_u);
+            for (int v = 0; v < a.V; v++) a.np1[(int64_t)v * a.N + p] = PSV(v);
             return;
         case SX_EQ_LINEAR_ADVECTION_1D: {      // src/testModels.jl:15
             const double e = -(par[SX_P_C0] * PS(0, a.s_r)) + (par[SX_P_K] * PS(0, a.s_rr));
-            ab_step(a, 0, p, PS(0, a.s_u), e);
-            for (int v = 1; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+            ab_step(a, 0, p, PSV(0), e);
+            for (int v = 1; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
         } break;
         case SX_EQ_LINEAR_ADVECTION_RZ: {      // src/testModels.jl:40
             const double hr = PS(0, a.s_r);
-            const double e = (-PS(1, a.s_u) * hr) + (-PS(3, a.s_u) * PS(0, a.s_z)) +
+            const double e = (-PSV(1) * hr) + (-PSV(3) * PS(0, a.s_z)) +
                              (par[SX_P_K] * ((hr / r) + PS(0, a.s_rr) + PS(0, a.s_zz)));
-            ab_step(a, 0, p, PS(0, a.s_u), e);
-            for (int v = 1; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+            ab_step(a, 0, p, PSV(0), e);
+            for (int v = 1; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
         } break;
         case SX_EQ_LINEAR_ADVECTION_RL:        // src/testModels.jl:62-68
         case SX_EQ_LINEAR_ADVECTION_RLZ: {     // src/testModels.jl:93
             const double hr = PS(0, a.s_r), hl = PS(0, a.s_l);
-            double e = (-PS(1, a.s_u) * hr) - (PS(2, a.s_u) * (hl / r));
+            double e = (-PSV(1) * hr) - (PSV(2) * (hl / r));
             if (a.eq == SX_EQ_LINEAR_ADVECTION_RLZ || par[SX_P_K] > 0.0)
                 e += par[SX_P_K] * ((hr / r) + PS(0, a.s_rr) + (PS(0, a.s_ll) / (r * r)));
-            ab_step(a, 0, p, PS(0, a.s_u), e);
-            for (int v = 1; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+            ab_step(a, 0, p, PSV(0), e);
+            for (int v = 1; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
         } break;
         case SX_EQ_ONEWAY_SW_SLAB:             // src/shallowWaterModels.jl:60-108
         case SX_EQ_TWOWAY_SW_SLAB: {           // src/shallowWaterModels.jl:176-228
             const double g = par[SX_P_G], K = par[SX_P_K], Cd = par[SX_P_CD], Hfree = par[SX_P_HFREE],
                          Hb = par[SX_P_HB], f = par[SX_P_F];
-            const double h = PS(0, a.s_u), hr = PS(0, a.s_r), hl = PS(0, a.s_l);
-            const double ug = PS(1, a.s_u), ugr = PS(1, a.s_r), ugl = PS(1, a.s_l);
-            const double vg = PS(2, a.s_u), vgr = PS(2, a.s_r), vgl = PS(2, a.s_l);
-            const double ub = PS(3, a.s_u), ubr = PS(3, a.s_r), ubrr = PS(3, a.s_rr), ubl = PS(3, a.s_l), ubll = PS(3, a.s_ll);
-            const double vb = PS(4, a.s_u), vbr = PS(4, a.s_r), vbrr = PS(4, a.s_rr), vbl = PS(4, a.s_l), vbll = PS(4, a.s_ll);
+            const double h = PSV(0), hr = PS(0, a.s_r), hl = PS(0, a.s_l);
+            const double ug = PSV(1), ugr = PS(1, a.s_r), ugl = PS(1, a.s_l);
+            const double vg = PSV(2), vgr = PS(2, a.s_r), vgl = PS(2, a.s_l);
+            const double ub = PSV(3), ubr = PS(3, a.s_r), ubrr = PS(3, a.s_rr), ubl = PS(3, a.s_l), ubll = PS(3, a.s_ll);
+            const double vb = PSV(4), vbr = PS(4, a.s_r), vbrr = PS(4, a.s_rr), vbl = PS(4, a.s_l), vbll = PS(4, a.s_ll);
             const double U = 0.78 * sqrt((ub * ub) + (vb * vb));
             const double w = -Hb * ((ub / r) + ubr + (vbl / r));
-            a.physw[((int64_t)a.s_u * a.V + 5) * a.N + p] = w;
+            a.P.val[(int64_t)5 * a.N + p] = w;
             const double w_ = 0.5 * fabs(w) - w;
             double e0 = ((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)));
             if (a.eq == SX_EQ_TWOWAY_SW_SLAB) e0 += -(Hfree + h) * w * par[SX_P_S1];
@@ -665,11 +675,11 @@ __global__ void k_phys_pointwise(PhysArgs a) {
             ab_step(a, 3, p, ub, e3);
             ab_step(a, 4, p, vb, e4);
             diag_step(a, 5, p, w);
-            for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+            for (int v = 6; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
         } break;
         case SX_EQ_LINEAR_ACOUSTIC_RZ: {
             const double K = par[SX_P_K], pxi = par[SX_P_PXI_BAR];
-            const double u = PS(3, a.s_u), w = PS(4, a.s_u);
+            const double u = PSV(3), w = PSV(4);
             double e[5];
             for (int v = 0; v < 5; v++) e[v] = (-u * PS(v, a.s_r)) + (-w * PS(v, a.s_z));
             const double d0 = K * (PS(0, a.s_rr) + PS(0, a.s_zz)), d2 = K * (PS(2, a.s_rr) + PS(2, a.s_zz));
@@ -681,7 +691,7 @@ __global__ void k_phys_pointwise(PhysArgs a) {
             e[3] = e[3] + (-(pxi * xir)) + d3;
             e[4] = e[4] + (-(pxi * xiz)) + d4;
             for (int v = 0; v < 5; v++) {
-                ab_step(a, v, p, PS(v, a.s_u), e[v]);
+                ab_step(a, v, p, PSV(v), e[v]);
                 a.In[(int64_t)v * a.N + p] = (v == 1) ? -wz : (v == 4) ? -(pxi * xiz) : 0.0;
             }
         } break;
@@ -692,7 +702,8 @@ __global__ void k_phys_pointwise(PhysArgs a) {
 // Oneway_ShallowWater_HeightResolvedBL (src/shallowWaterModels.jl:346-511). One workgroup handles `cpb` columns;
 // thread (c, k) owns level k of column c. The three per-column Chebyshev operators (integral of the divergence,
 // derivative of the two vertical fluxes) are dense nz x nz mat-vecs with the operands staged in LDS.
-__global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgs a, int cpb) {
+template <class ST>
+__global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgsT<ST> a, int cpb) {
     extern __shared__ double sm[];
     const int nz = a.nz;
     const int k = threadIdx.x % nz, cl = threadIdx.x / nz;
@@ -708,11 +719,11 @@ __global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgs a, int cpb) {
     double ub = 0, ubr = 0, ubrr = 0, ubl = 0, ubll = 0, ubz = 0, vb = 0, vbr = 0, vbrr = 0, vbl = 0, vbll = 0, vbz = 0;
     if (live) {
         r = a.r[col];
-        h = PS(0, a.s_u); hr = PS(0, a.s_r); hl = PS(0, a.s_l);
-        ug = PS(1, a.s_u); ugr = PS(1, a.s_r); ugl = PS(1, a.s_l);
-        vg = PS(2, a.s_u); vgr = PS(2, a.s_r); vgl = PS(2, a.s_l);
-        ub = PS(3, a.s_u); ubr = PS(3, a.s_r); ubrr = PS(3, a.s_rr); ubl = PS(3, a.s_l); ubll = PS(3, a.s_ll); ubz = PS(3, a.s_z);
-        vb = PS(4, a.s_u); vbr = PS(4, a.s_r); vbrr = PS(4, a.s_rr); vbl = PS(4, a.s_l); vbll = PS(4, a.s_ll); vbz = PS(4, a.s_z);
+        h = PSV(0); hr = PS(0, a.s_r); hl = PS(0, a.s_l);
+        ug = PSV(1); ugr = PS(1, a.s_r); ugl = PS(1, a.s_l);
+        vg = PSV(2); vgr = PS(2, a.s_r); vgl = PS(2, a.s_l);
+        ub = PSV(3); ubr = PS(3, a.s_r); ubrr = PS(3, a.s_rr); ubl = PS(3, a.s_l); ubll = PS(3, a.s_ll); ubz = PS(3, a.s_z);
+        vb = PSV(4); vbr = PS(4, a.s_r); vbrr = PS(4, a.s_rr); vbl = PS(4, a.s_l); vbll = PS(4, a.s_ll); vbz = PS(4, a.s_z);
         const double S = sqrt((ubz * ubz) + (vbz * vbz));
         const double l = 1.0 / ((1.0 / (0.4 * a.z[k])) + (1.0 / 80.0));
         const double Kv = (l * l) * S;
@@ -745,7 +756,7 @@ __global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgs a, int cpb) {
         vdu += md * xu[j];
         vdv += md * xv[j];
     }
-    a.physw[((int64_t)a.s_u * a.V + 5) * a.N + p] = wb;
+    a.P.val[(int64_t)5 * a.N + p] = wb;
     const double e0 = ((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)));
     const double e1 = ((-vg * ugl / r) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg / r)));
     const double e2 = ((-vg * vgl / r) + (-ug * vgr)) + (-g * (hl / r)) + (-ug * (f + (vg / r)));
@@ -759,7 +770,7 @@ __global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgs a, int cpb) {
     ab_step(a, 3, p, ub, e3);
     ab_step(a, 4, p, vb, e4);
     diag_step(a, 5, p, wb);
-    for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+    for (int v = 6; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
 }
 
 // MFMA variant of the same equation set for zDim = NZ (multiple of 16): 16 columns per workgroup. The three column
@@ -768,14 +779,10 @@ __global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgs a, int cpb) {
 // (L2-resident) operator, B and the result tiles live in LDS, column-major with a 2-double pad (bank-conflict free).
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-// NODE = true ("radial last", uniform rings): instead of reading ring-wise derivative slots from `physical`, the thread
-// combines the node-space transforms G of the ring's 4 spline nodes with the basis weights phi, phi', phi'' itself
-// (value / d/dr / d2/dr2 from the value transform; d/dlambda, d2/dlambda2, d/dz from their own transforms), so the
-// 22 physical planes of these rings are never written to or read from HBM.
-// CPB columns per workgroup (<= 16, the MFMA tile width): 8 gives two resident workgroups per CU, so one workgroup's
-// load phase overlaps the other's MFMA / store phase (the unused tile columns cost nothing that matters).
-template <int NZ, bool NODE, int CPB>
-__global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgs a) {
+// CPB columns per workgroup (<= 16, the MFMA tile width).  Used for the rings on the ring-wise path (all of them without
+// the node-space inverse, the inner ones with it; k_phys_hrbl_cell takes the rest).
+template <int NZ, int CPB, class ST>
+__global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
     constexpr int CS = NZ + 2;                     // column stride in LDS
     __shared__ double X[3][16 * CS];               // div, Kv*ubz, Kv*vbz   -> inputs (columns >= CPB unused)
     __shared__ double Y[3][16 * CS];               // wb,  d/dz(...), d/dz(...) -> outputs
@@ -804,38 +811,11 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgs a) {
         r = a.r[col];
         ri = 1.0 / r;
         ri2 = ri * ri;
-        if (NODE) {
-            const int ring = (int)(col / a.L);
-            const int lam = (int)(col - (int64_t)ring * a.L);
-            const int64_t gp = ((int64_t)(ring / MUBAR) * a.L + lam) * NZ + k;      // node row of the ring's cell, this (lambda, z)
-            const int64_t gs = (int64_t)a.L * NZ;                                   // stride between nodes
-            const double *w0 = a.phi + (int64_t)ring * 4, *w1 = w0 + (int64_t)a.nrings * 4, *w2 = w1 + (int64_t)a.nrings * 4;
-            const double p00 = w0[0], p01 = w0[1], p02 = w0[2], p03 = w0[3];
-            const double p10 = w1[0], p11 = w1[1], p12 = w1[2], p13 = w1[3];
-            const double p20 = w2[0], p21 = w2[1], p22 = w2[2], p23 = w2[3];
-#define GN(v, s, j) a.G[((int64_t)(s) * a.V + (v)) * a.NG + gp + (j) * gs]
-#define NODE3(v, val, dr) { const double q0 = GN(v, a.s_u, 0), q1 = GN(v, a.s_u, 1), q2 = GN(v, a.s_u, 2), q3 = GN(v, a.s_u, 3); \
-                            val = p00 * q0 + p01 * q1 + p02 * q2 + p03 * q3; dr = p10 * q0 + p11 * q1 + p12 * q2 + p13 * q3; }
-#define NODE4(v, val, dr, drr) { const double q0 = GN(v, a.s_u, 0), q1 = GN(v, a.s_u, 1), q2 = GN(v, a.s_u, 2), q3 = GN(v, a.s_u, 3); \
-                            val = p00 * q0 + p01 * q1 + p02 * q2 + p03 * q3; dr = p10 * q0 + p11 * q1 + p12 * q2 + p13 * q3;    \
-                            drr = p20 * q0 + p21 * q1 + p22 * q2 + p23 * q3; }
-#define NODE1(v, s) (p00 * GN(v, s, 0) + p01 * GN(v, s, 1) + p02 * GN(v, s, 2) + p03 * GN(v, s, 3))
-            NODE3(0, h, hr); hl = NODE1(0, a.s_l);
-            NODE3(1, ug, ugr); ugl = NODE1(1, a.s_l);
-            NODE3(2, vg, vgr); vgl = NODE1(2, a.s_l);
-            NODE4(3, ub, ubr, ubrr); ubl = NODE1(3, a.s_l); ubll = NODE1(3, a.s_ll); ubz = NODE1(3, a.s_z);
-            NODE4(4, vb, vbr, vbrr); vbl = NODE1(4, a.s_l); vbll = NODE1(4, a.s_ll); vbz = NODE1(4, a.s_z);
-#undef GN
-#undef NODE3
-#undef NODE4
-#undef NODE1
-        } else {
-            h = PS(0, a.s_u); hr = PS(0, a.s_r); hl = PS(0, a.s_l);
-            ug = PS(1, a.s_u); ugr = PS(1, a.s_r); ugl = PS(1, a.s_l);
-            vg = PS(2, a.s_u); vgr = PS(2, a.s_r); vgl = PS(2, a.s_l);
-            ub = PS(3, a.s_u); ubr = PS(3, a.s_r); ubrr = PS(3, a.s_rr); ubl = PS(3, a.s_l); ubll = PS(3, a.s_ll); ubz = PS(3, a.s_z);
-            vb = PS(4, a.s_u); vbr = PS(4, a.s_r); vbrr = PS(4, a.s_rr); vbl = PS(4, a.s_l); vbll = PS(4, a.s_ll); vbz = PS(4, a.s_z);
-        }
+        h = PSV(0); hr = PS(0, a.s_r); hl = PS(0, a.s_l);
+        ug = PSV(1); ugr = PS(1, a.s_r); ugl = PS(1, a.s_l);
+        vg = PSV(2); vgr = PS(2, a.s_r); vgl = PS(2, a.s_l);
+        ub = PSV(3); ubr = PS(3, a.s_r); ubrr = PS(3, a.s_rr); ubl = PS(3, a.s_l); ubll = PS(3, a.s_ll); ubz = PS(3, a.s_z);
+        vb = PSV(4); vbr = PS(4, a.s_r); vbrr = PS(4, a.s_rr); vbl = PS(4, a.s_l); vbll = PS(4, a.s_ll); vbz = PS(4, a.s_z);
         const double S = sqrt((ubz * ubz) + (vbz * vbz));
         const double l = 1.0 / ((1.0 / (0.4 * a.z[k])) + (1.0 / 80.0));
         const double Kv = (l * l) * S;
@@ -881,7 +861,7 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgs a) {
     __syncthreads();
     if (!live) return;
     const double wb = Y[0][cl * CS + k], vdu = Y[1][cl * CS + k], vdv = Y[2][cl * CS + k];
-    a.physw[((int64_t)a.s_u * a.V + 5) * a.N + p] = wb;
+    a.P.val[(int64_t)5 * a.N + p] = wb;
     const double e0 = ((-vg * hl * ri) + (-ug * hr)) + (-(Hfree + h) * ((ug * ri) + ugr + (vgl * ri)));
     const double e1 = ((-vg * ugl * ri) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg * ri)));
     const double e2 = ((-vg * vgl * ri) + (-ug * vgr)) + (-g * (hl * ri)) + (-ug * (f + (vg * ri)));
@@ -901,7 +881,7 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgs a) {
         a.np1[o] = un;
     }
     diag_step(a, 5, p, wb);
-    for (int v = 6; v < a.V; v++) ab_step(a, v, p, PS(v, a.s_u), 0.0);
+    for (int v = 6; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
 }
 
 // Cell-wise node-space variant ("radial last", uniform rings): one workgroup = LAM azimuths x NZ levels of ONE radial
@@ -910,8 +890,8 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgs a) {
 // enters the CU once instead of three times (the ring-wise grouping was bound by L1 fill rate, not by HBM).
 // The column operators of the 3 x LAM columns run as one f64-MFMA batch; the fields are re-formed from the registers
 // after it, ring by ring, for the tendencies.
-template <int NZ, int LAM>
-__global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgs a, int cell0) {
+template <int NZ, int LAM, class ST>
+__global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a, int cell0) {
     constexpr int CS = NZ + 2;
     constexpr int NCOL = 3 * LAM, NT = (NCOL + 15) / 16;
     __shared__ double X[3][NT * 16 * CS];
@@ -928,15 +908,21 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgs a, int 
     // node transforms: [transform][node]
     double qh[4], qhl[4], qug[4], qugl[4], qvg[4], qvgl[4];
     double qub[4], qubl[4], qubll[4], qubz[4], qvb[4], qvbl[4], qvbll[4], qvbz[4];
-#define GLOAD(dst, v, s)                                                                           \
+#define GLOADV(dst, v)                                                                             \
     {                                                                                              \
-        const double *gq = a.G + ((int64_t)(s) * a.V + (v)) * a.NG + gp;                           \
+        const double *gq = a.G.val + (int64_t)(v) * a.NG + gp;                                     \
         dst[0] = gq[0]; dst[1] = gq[gs]; dst[2] = gq[2 * gs]; dst[3] = gq[3 * gs];                 \
     }
-    GLOAD(qub, 3, a.s_u) GLOAD(qubz, 3, a.s_z) GLOAD(qvbz, 4, a.s_z) GLOAD(qvbl, 4, a.s_l) GLOAD(qvb, 4, a.s_u)
-    GLOAD(qh, 0, a.s_u) GLOAD(qhl, 0, a.s_l) GLOAD(qug, 1, a.s_u) GLOAD(qugl, 1, a.s_l) GLOAD(qvg, 2, a.s_u) GLOAD(qvgl, 2, a.s_l)
+#define GLOAD(dst, v, s)                                                                           \
+    {                                                                                              \
+        const ST *gq = a.G.der + ((int64_t)((s) - 1) * a.V + (v)) * a.NG + gp;                     \
+        dst[0] = gq[0]; dst[1] = gq[gs]; dst[2] = gq[2 * gs]; dst[3] = gq[3 * gs];                 \
+    }
+    GLOADV(qub, 3) GLOAD(qubz, 3, a.s_z) GLOAD(qvbz, 4, a.s_z) GLOAD(qvbl, 4, a.s_l) GLOADV(qvb, 4)
+    GLOADV(qh, 0) GLOAD(qhl, 0, a.s_l) GLOADV(qug, 1) GLOAD(qugl, 1, a.s_l) GLOADV(qvg, 2) GLOAD(qvgl, 2, a.s_l)
     GLOAD(qubl, 3, a.s_l) GLOAD(qubll, 3, a.s_ll) GLOAD(qvbll, 4, a.s_ll)
 #undef GLOAD
+#undef GLOADV
     // tendency history of ring mu = 0, fetched now (latency hidden behind the operator phase); the next ring's is
     // fetched while the current ring is finished
     double e1h[MUBAR][5], e2h[MUBAR][5];
@@ -1023,7 +1009,7 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgs a, int 
         const double vbl = DOT(w0, qvbl), vbll = DOT(w0, qvbll), vbz = DOT(w0, qvbz);
         const int c = mu * LAM + ll;
         const double wb = Y[0][c * CS + k], vdu = Y[1][c * CS + k], vdv = Y[2][c * CS + k];
-        a.physw[((int64_t)a.s_u * a.V + 5) * a.N + p] = wb;
+        a.P.val[(int64_t)5 * a.N + p] = wb;
         const double e0 = ((-vg * hl * ri) + (-ug * hr)) + (-(Hfree + h) * ((ug * ri) + ugr + (vgl * ri)));
         const double e1 = ((-vg * ugl * ri) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg * ri)));
         const double e2 = ((-vg * vgl * ri) + (-ug * vgr)) + (-g * (hl * ri)) + (-ug * (f + (vg * ri)));
@@ -1142,17 +1128,20 @@ void launch_rl_inverse(sx_handle *h, bool full) {
     const double *az = h->has_z ? h->d_Az : h->d_A + (int64_t)h->cell0 * h->C;
     const int64_t azrow = h->has_z ? (int64_t)h->V * 3 * h->nz * h->K2 : h->C;
     dim3 g((h->nz + ZC - 1) / ZC, h->V, h->nrings);
-    hipLaunchKernelGGL(k_rl_inverse, g, dim3(256), lds, h->stream, az, h->d_phys, h->d_phi, h->d_L, h->d_kmax, h->d_pstart,
-                       h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2, h->nrings, h->N, azrow,
-                       h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6], h->has_l, cstride, mask);
+#define RL_ARGS h->d_phi, h->d_L, h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2,   \
+                h->nrings, h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6],   \
+                h->has_l, cstride, mask
+    if (h->f32) hipLaunchKernelGGL(k_rl_inverse<float>, g, dim3(256), lds, h->stream, az, planes_of<float>(h->d_phys, h->V, h->N), RL_ARGS);
+    else hipLaunchKernelGGL(k_rl_inverse<double>, g, dim3(256), lds, h->stream, az, planes_of<double>(h->d_phys, h->V, h->N), RL_ARGS);
+#undef RL_ARGS
     HIPCHK(hipGetLastError());
     timer_end(h);
 }
 
-static PhysArgs phys_args(sx_handle *h, int t) {
-    PhysArgs a;
-    a.phys = h->d_phys;
-    a.physw = h->d_phys;
+template <class ST>
+static PhysArgsT<ST> phys_args(sx_handle *h, int t) {
+    PhysArgsT<ST> a;
+    a.P = planes_of<ST>(h->d_phys, h->V, h->N);
     a.En = h->d_E[h->rot % 3];
     a.E1 = h->d_E[(h->rot + 1) % 3];
     a.E2 = h->d_E[(h->rot + 2) % 3];
@@ -1165,7 +1154,7 @@ static PhysArgs phys_args(sx_handle *h, int t) {
     a.s_z = h->slot[5]; a.s_zz = h->slot[6];
     a.ts = h->ts;
     for (int i = 0; i < SX_NPARAMS; i++) a.par[i] = h->par[i];
-    a.col0 = 0; a.col1 = h->Nh; a.G = nullptr; a.phi = nullptr; a.NG = 0; a.L = 1; a.nrings = h->nrings;
+    a.col0 = 0; a.col1 = h->Nh; a.G = Planes<ST>{nullptr, nullptr}; a.phi = nullptr; a.NG = 0; a.L = 1; a.nrings = h->nrings;
     return a;
 }
 
@@ -1173,19 +1162,21 @@ static PhysArgs phys_args(sx_handle *h, int t) {
 // expdot_nm1 and the previous nm1 becomes nm2. rot decreases by one (mod 3) per step.
 constexpr int PCPB = 16;      // columns per workgroup of the MFMA HRBL kernel (8: two resident workgroups, measured slower)
 
-void launch_physics(sx_handle *h, int t) {
+template <class ST>
+static void launch_physics_t(sx_handle *h, int t) {
     if (h->eq != SX_EQ_NONE && t == 1) h->rot = 0;
-    PhysArgs a = phys_args(h, t);
+    PhysArgsT<ST> a = phys_args<ST>(h, t);
     if (h->eq == SX_EQ_ONEWAY_SW_HRBL && (h->nz == 64 || h->nz == 32)) {
         // rings [0, R_in): ring-wise physical slots; rings [R_in, nrings): node-space transforms (node_mode only)
         const int64_t split = (h->node_mode && h->node_active) ? (int64_t)h->R_in * h->uniform_L : h->Nh;
-        a.G = h->d_G; a.phi = h->d_phi; a.NG = h->NG; a.L = h->uniform_L; a.nrings = h->nrings;
+        if (h->d_G) a.G = planes_of<ST>(h->d_G, h->V, h->NG);
+        a.phi = h->d_phi; a.NG = h->NG; a.L = h->uniform_L; a.nrings = h->nrings;
         if (split > 0) {
             const int id = timer_id(h, split < h->Nh ? "k_phys_hrbl_inner" : "k_phys_hrbl");
             timer_begin(h, id);
             a.col0 = 0; a.col1 = split;
-            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, false, PCPB>), grid1(split, PCPB), dim3(PCPB * 64), 0, h->stream, a);
-            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, false, PCPB>), grid1(split, PCPB), dim3(PCPB * 32), 0, h->stream, a);
+            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, PCPB, ST>), grid1(split, PCPB), dim3(PCPB * 64), 0, h->stream, a);
+            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, PCPB, ST>), grid1(split, PCPB), dim3(PCPB * 32), 0, h->stream, a);
             HIPCHK(hipGetLastError());
             timer_end(h);
         }
@@ -1196,10 +1187,10 @@ void launch_physics(sx_handle *h, int t) {
             const int ncell = (h->nrings - h->R_in) / MUBAR;         // R_in is a multiple of 3 (sx_create)
             if (h->nz == 64) {
                 constexpr int LAM = 4;
-                hipLaunchKernelGGL((k_phys_hrbl_cell<64, LAM>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 64), 0, h->stream, a, h->R_in / MUBAR);
+                hipLaunchKernelGGL((k_phys_hrbl_cell<64, LAM, ST>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 64), 0, h->stream, a, h->R_in / MUBAR);
             } else {
                 constexpr int LAM = 8;
-                hipLaunchKernelGGL((k_phys_hrbl_cell<32, LAM>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 32), 0, h->stream, a, h->R_in / MUBAR);
+                hipLaunchKernelGGL((k_phys_hrbl_cell<32, LAM, ST>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 32), 0, h->stream, a, h->R_in / MUBAR);
             }
             HIPCHK(hipGetLastError());
             timer_end(h);
@@ -1210,13 +1201,13 @@ void launch_physics(sx_handle *h, int t) {
         const int cpb = h->nz >= 256 ? 1 : 256 / h->nz;
         const int bs = cpb * h->nz;
         const size_t lds = sizeof(double) * 5 * cpb * h->nz;
-        hipLaunchKernelGGL(k_phys_hrbl, grid1(h->Nh, cpb), dim3(bs), lds, h->stream, a, cpb);
+        hipLaunchKernelGGL(k_phys_hrbl<ST>, grid1(h->Nh, cpb), dim3(bs), lds, h->stream, a, cpb);
         HIPCHK(hipGetLastError());
         timer_end(h);
     } else {
         const int id = timer_id(h, "k_phys_pointwise");
         timer_begin(h, id);
-        hipLaunchKernelGGL(k_phys_pointwise, grid1(h->N, 256), dim3(256), 0, h->stream, a);
+        hipLaunchKernelGGL(k_phys_pointwise<ST>, grid1(h->N, 256), dim3(256), 0, h->stream, a);
         HIPCHK(hipGetLastError());
         timer_end(h);
     }
@@ -1237,6 +1228,11 @@ void launch_physics(sx_handle *h, int t) {
         timer_end(h);
     }
     if (h->eq != SX_EQ_NONE) h->rot = (h->rot + 2) % 3;
+}
+
+void launch_physics(sx_handle *h, int t) {
+    if (h->f32) launch_physics_t<float>(h, t);
+    else launch_physics_t<double>(h, t);
 }
 
 void launch_fl_forward(sx_handle *h) {
@@ -1280,24 +1276,14 @@ void launch_sb(sx_handle *h) {
     const int id = timer_id(h, "k_sb");
     timer_begin(h, id);
     const int64_t plane = (int64_t)h->V * h->nz * h->K2;
-    double *out = h->has_z ? h->d_Bz : h->d_Btile;
     dim3 g((unsigned)((plane + 255) / 256), h->nbt);
-    hipLaunchKernelGGL(k_sb, g, dim3(256), 0, h->stream, h->d_Fl, out, h->d_phi, h->d_wq, h->ncells, plane);
+    hipLaunchKernelGGL(k_sb, g, dim3(256), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->ncells, plane);
     HIPCHK(hipGetLastError());
     timer_end(h);
 }
 
-void launch_zf(sx_handle *h) {
-    return;                // the vertical forward transform is fused into k_sbz (launch_sb)
-    if (!h->has_z) return;
-    const int id = timer_id(h, "k_zf");
-    timer_begin(h, id);
-    dim3 g((h->K2 + 63) / 64, h->V, h->nbt);
-    hipLaunchKernelGGL(k_colmat, g, dim3(64, 4), sizeof(double) * 64 * h->nz, h->stream, h->d_Bz, h->d_Btile, h->d_CB,
-                       h->d_jobs_zf, h->nz, h->Zb, h->K2, (int64_t)h->V * h->nz * h->K2, h->C, 0);
-    HIPCHK(hipGetLastError());
-    timer_end(h);
-}
+// the vertical forward transform is fused into k_sbz / k_sbw (launch_sb)
+void launch_zf(sx_handle *) {}
 
 void launch_solve(sx_handle *h) {
     const int id = timer_id(h, "k_solve");
@@ -1353,9 +1339,12 @@ void launch_halo_add(sx_handle *h, const double *recv) {
 
 void launch_nan_check(sx_handle *h) {
     HIPCHK(hipMemsetAsync(h->d_flag, 0, sizeof(int), h->stream));
-    const int64_t n = (int64_t)h->V * h->N;     // slot of the values is a contiguous [V][N] block
-    hipLaunchKernelGGL(k_nan_check, dim3(2048), dim3(256), 0, h->stream, h->d_phys + (int64_t)h->slot[0] * h->V * h->N, n,
-                       h->d_flag);
+    // checkCFL (src/semiimplicit.jl:737-751) scans physical[:, v, 1] right after a tileTransform!.  Here the scan runs
+    // over var_np1 = value + ts * tendency of the last step (the initial values before the first step): a NaN in any
+    // value propagates into it, and unlike `physical` it is complete after every sx_advance (slot masks and the
+    // node-space inverse leave parts of `physical` untouched between outputs).
+    const int64_t n = (int64_t)h->V * h->N;
+    hipLaunchKernelGGL(k_nan_check, dim3(2048), dim3(256), 0, h->stream, h->d_np1, n, h->d_flag);
     HIPCHK(hipGetLastError());
 }
 

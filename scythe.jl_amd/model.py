@@ -92,6 +92,7 @@ class GridParameters:
     # extensions (not in the reference): uniform ring table and a separate k = 0 inner BC
     ring_uniform_L: int = 0
     BCL_k0: Optional[Dict] = None
+    storage: str = "f64"       # "f32": physical and the transform intermediates are stored as fp32 (sx_grid_desc.storage_f32)
 
     def __post_init__(self):
         if self.rDim is None:
@@ -153,6 +154,9 @@ def grid_desc(patch: GridParameters, tile_cell0=0, tile_num_cells=None, tile_num
     d.tile_cell0 = tile_cell0
     d.tile_num_cells = patch.num_cells if tile_num_cells is None else tile_num_cells
     d.tile_num = tile_num
+    if patch.storage not in ("f64", "f32"):
+        raise ValueError("GridParameters.storage must be 'f64' or 'f32'")
+    d.storage_f32 = 1 if patch.storage == "f32" else 0
     return d, keep
 
 
@@ -215,7 +219,8 @@ class Grid:
             num_cells=self.ncells, l_q=patch.l_q, BCL={k: CubicBSpline.R0 for k in patch.vars},
             BCR={k: CubicBSpline.R0 for k in patch.vars}, lDim=int(dims.n_hpoints) if "L" in patch.geometry else 0,
             zmin=patch.zmin, zmax=patch.zmax, zDim=patch.zDim, b_zDim=patch.b_zDim, BCB=patch.BCB, BCT=patch.BCT,
-            vars=patch.vars, spectralIndexL=tile_cell0 + 1, tile_num=tile_num, ring_uniform_L=patch.ring_uniform_L)
+            vars=patch.vars, spectralIndexL=tile_cell0 + 1, tile_num=tile_num, ring_uniform_L=patch.ring_uniform_L,
+            storage=patch.storage)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -140,11 +140,11 @@ class OracleModel:
         return self.m.A
 
 
-def hip_params(case):
+def hip_params(case, storage="f64"):
     import scythe_jl_amd as S
     g = dict(case["grid"])
     ring_L = g.pop("ring_L", None)
-    gp = S.GridParameters(ring_uniform_L=ring_L or 0, **g)
+    gp = S.GridParameters(ring_uniform_L=ring_L or 0, storage=storage, **g)
     mp = S.ModelParameters(ts=case["ts"], equation_set=case["eq"], grid_params=gp, physical_params=dict(case["par"]),
                            options={"semiimplicit": case.get("semiimplicit", False)})
     return gp, mp
@@ -153,9 +153,9 @@ def hip_params(case):
 class HipModel:
     """The product path: tiles are libscythe_hip handles, exchange on device buffers."""
 
-    def __init__(self, case, num_tiles=1, device="cuda", exchange="a2a"):
+    def __init__(self, case, num_tiles=1, device="cuda", exchange="a2a", storage="f64"):
         import scythe_jl_amd as S
-        self.gp, self.mp = hip_params(case)
+        self.gp, self.mp = hip_params(case, storage)
         self.run = S.ModelRun(self.mp, num_tiles=num_tiles, device=device, exchange=exchange)
         vals = []
         for g in self.run.tiles:

@@ -29,7 +29,9 @@ def test_library_exports_every_declared_symbol():
     lib = C.CDLL(S.LIB_PATH)
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert S.load().sx_abi_version() == 1
+    import re
+    want = int(re.search(r"#define SX_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "scythe_hip.h")).read()).group(1))
+    assert S.load().sx_abi_version() == want
 
 
 def test_equation_set_names():

@@ -97,3 +97,51 @@ def test_tiles_on_one_gpu_match_single_patch_oracle(maker, kw, ntiles, exchange)
     solve (the reference's protocol), "a2a" = transposed solve (pack / all-to-all / solve / all-to-all / unpack)."""
     case = maker(**kw)
     assert _run(case, 4, num_tiles=ntiles, exchange=exchange) < TOL
+
+
+def test_check_nan_sees_a_nan_on_the_node_space_path():
+    """checkCFL: a NaN planted in an outer ring (whose `physical` planes the node-space path never writes during
+    sx_advance) must be reported after the next step; a clean run reports nothing."""
+    import scythe_jl_amd as S
+    case = cases.rlz_hrbl(num_cells=8, zDim=32, ring_L=32)
+    m = cases.HipModel(case)
+    m.step()
+    g = m.run.tiles[0]
+    assert not g.check_nan()
+    pts = S.getGridpoints(g)
+    vals = case["ic"](pts.reshape(len(pts), -1))
+    vals[-5, 1] = np.nan
+    m.run.set_initial_conditions([vals])
+    m.run.t = 0
+    m.step()
+    assert g.check_nan()
+
+
+# fp32-storage mode (SURVEY.md 8(d) config 5): the derivative slots of `physical` and of the node-space transforms are
+# stored as fp32; the value slot, all arithmetic, every spectral array, the solve and the time-stepping state stay fp64.
+# Declared tolerance against the fp64 oracle after 3 steps: values 1e-6 of the variable's scale (fp32 rounding reaches
+# them only through ts * tendency; the largest case is HRBL at zDim 64, where the Chebyshev d/dz operator, norm
+# O(zDim^2), acts on the fp32-rounded vertical flux: 3.6e-7; all other cases stay below 5e-9), derivative slots 5e-5 of
+# the slot's scale (one fp32 rounding, 6e-8, plus the k^2-amplified echo of the value error in d2/dlambda2).
+F32_TOL_VAL, F32_TOL_DER = 1e-6, 5e-5
+
+
+@pytest.mark.parametrize("maker,kw", [(cases.kat_r, {}),
+                                       (cases.rz_advection, {}),
+                                       (cases.rl_slab, {"num_cells": 6}),
+                                       (cases.rl_slab, {"num_cells": 6, "ring_L": 32}),
+                                       (cases.rlz_hrbl, {"num_cells": 4, "zDim": 12}),
+                                       (cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}),
+                                       (cases.rlz_hrbl, {"num_cells": 6, "zDim": 64, "ring_L": 16})])
+def test_fp32_storage_mode_within_declared_tolerance(maker, kw):
+    case = maker(**kw)
+    ref = cases.OracleModel(case)
+    hip = cases.HipModel(case, storage="f32")
+    for _ in range(3):
+        ref.step()
+        hip.step()
+    a, b = hip.physical(), ref.physical()
+    err_val = cases.rel_err_per_var(a[:, :, :1], b[:, :, :1])
+    err_all = cases.rel_err_per_var(a, b)
+    assert err_val < F32_TOL_VAL, err_val
+    assert 1e-9 < err_all < F32_TOL_DER, err_all      # the lower bound proves the fp32 path really ran
