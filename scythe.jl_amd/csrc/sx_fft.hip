@@ -20,9 +20,14 @@ namespace sx {
         if (e_ != hipSuccess) set_error(std::string(#x) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
-constexpr int FZC = 16;        // z levels per workgroup
-constexpr int FNP = FZC / 2;   // complex transforms per slot and workgroup
-constexpr int SKEW = 2;        // complex elements of skew between transform regions (bank spreading when L < 256)
+// z levels per workgroup (FZC) and complex transforms per slot and workgroup (FNP = FZC / 2).  A transform of length L
+// is owned by L/4 lanes: one wave up to L = 256 (16 levels per 512-thread workgroup, wave-local passes), two waves for
+// L = 512 (8 levels, the passes then synchronise through an LDS-only workgroup barrier).
+// SKEW: complex elements between transform regions (bank spreading when L < 256; 0 at L = 512 so that the two LDS sets
+// of the inverse are exactly 64 KB).
+template <int LOGL> struct FftCfg {
+    static constexpr int FZC = (LOGL <= 8) ? 16 : 8, FNP = FZC / 2, LOGZ = (LOGL <= 8) ? 4 : 3, SKEW = (LOGL <= 8) ? 2 : 0;
+};
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -43,6 +48,13 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// orders the LDS traffic of the lanes that share one transform
+template <int LOGL>
+__device__ __forceinline__ void pass_sync() {
+    if (LOGL <= 8) wave_sync();
+    else lds_barrier();
 }
 
 template <int LOGL>
@@ -99,9 +111,9 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw
             if (active) { last(j0, y0); last(j0 + Ns, y1); last(j0 + 2 * Ns, y2); last(j0 + 3 * Ns, y3); }
             return;
         }
-        wave_sync();      // every lane has read its inputs before any lane overwrites them
+        pass_sync<LOGL>();      // every lane has read its inputs before any lane overwrites them
         if (active) { X[j0] = y0; X[j0 + Ns] = y1; X[j0 + 2 * Ns] = y2; X[j0 + 3 * Ns] = y3; }
-        wave_sync();
+        pass_sync<LOGL>();
         Ns <<= 2;
     }
     if (LOGL & 1) {       // final radix-2 pass, Ns = L/2: butterflies j = t and t + T
@@ -111,9 +123,9 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw
             b0 = X[t + T]; b1 = cmul(X[t + 3 * T], tw.r2b);
         }
         if (TO_LDS) {
-            wave_sync();
+            pass_sync<LOGL>();
             if (active) { X[t] = cadd(a0, a1); X[t + Ns] = csub(a0, a1); X[t + T] = cadd(b0, b1); X[t + T + Ns] = csub(b0, b1); }
-            wave_sync();
+            pass_sync<LOGL>();
         } else if (active) {
             last(t, cadd(a0, a1)); last(t + Ns, csub(a0, a1));
             last(t + T, cadd(b0, b1)); last(t + T + Ns, csub(b0, b1));
@@ -133,6 +145,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
     // NODE: the "rings" are radial NODES (uniform ring tables only): one Az row per unit, no radial combination;
     // the output is the node-space array G that the equation-set kernel combines with the basis weights itself.
     constexpr int L = 1 << LOGL, T = L / 4;
+    constexpr int FZC = FftCfg<LOGL>::FZC, FNP = FftCfg<LOGL>::FNP, LOGZ = FftCfg<LOGL>::LOGZ, SKEW = FftCfg<LOGL>::SKEW;
     extern __shared__ double2 smf[];
     const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * FZC;
     const int zc = min(FZC, nz - z0);
@@ -211,18 +224,18 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                 X[k2] = make_double2(c2.x - e2.y, c2.y + e2.x);
                 X[L - k2] = make_double2(c2.x + e2.y, e2.x - c2.y);
             }
-            wave_sync();
+            pass_sync<LOGL>();
             if (COPYOUT) {
                 // last pass goes back to LDS, then the whole workgroup writes full 128-byte lines
                 fft_inplace<LOGL, +1, true>(X, tw, t, active);
                 lds_barrier();       // also orders the previous slot's copy-out reads (other set) before that set is restaged
-                // thread -> (level zz, ring point l0 + 32 i): consecutive lanes cover the 16 levels of one point
+                // thread -> (level zz, ring point l0 + (512 / FZC) i): consecutive lanes cover the FZC levels of one point
                 const int zz = threadIdx.x & (FZC - 1);
                 const double *src = reinterpret_cast<const double *>(set + (zz >> 1) * (L + SKEW)) + (zz & 1);
                 auto copy_out = [&](auto *out) {
                     if (zz < zc) {
 #pragma unroll 4
-                        for (int l = threadIdx.x >> 4; l < L; l += (int)(blockDim.x >> 4)) out[(int64_t)l * nz + zz] = src[2 * l];
+                        for (int l = threadIdx.x >> LOGZ; l < L; l += (int)(blockDim.x >> LOGZ)) out[(int64_t)l * nz + zz] = src[2 * l];
                     }
                 };
                 if (slot == 0) copy_out(phys.val + (int64_t)v * N + p0 * nz + z0);
@@ -239,7 +252,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                         o[0] = (ST)y.x; if (hasb) o[1] = (ST)y.y;
                     }
                 });
-                wave_sync();      // the region is rewritten by the next slot
+                pass_sync<LOGL>();      // the region is rewritten by the next slot
             }
         }
     }
@@ -252,6 +265,7 @@ k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const 
                  const int64_t *__restrict__ pstart, const double2 *__restrict__ twg, const int64_t *__restrict__ phoff,
                  const double2 *__restrict__ ph, int V, int nz, int K2, int64_t N) {
     constexpr int L = 1 << LOGL, T = L / 4;
+    constexpr int FZC = FftCfg<LOGL>::FZC, FNP = FftCfg<LOGL>::FNP, LOGZ = FftCfg<LOGL>::LOGZ, SKEW = FftCfg<LOGL>::SKEW;
     extern __shared__ double2 smf[];
     const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * FZC;
     const int zc = min(FZC, nz - z0);
@@ -266,7 +280,7 @@ k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     const double *x = np1 + (int64_t)v * N + p0 * nz + z0;
     double *ba = (double *)smf;
     for (int o = tid; o < L * FZC; o += blockDim.x) {
-        const int zz = o & (FZC - 1), l = o >> 4;
+        const int zz = o & (FZC - 1), l = o >> LOGZ;
         const double val = (zz < zc) ? x[(int64_t)l * nz + zz] : 0.0;
         ba[2 * ((zz >> 1) * (L + SKEW) + l) + (zz & 1)] = val;
     }
@@ -303,11 +317,12 @@ static int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
 
 bool fft_path_ok(const sx_handle *h) {
     const int L = h->uniform_L;
-    return h->has_l && L >= 16 && L <= 256 && (L & (L - 1)) == 0;   // one transform = L/4 <= 64 lanes of one wave
+    return h->has_l && L >= 16 && L <= 512 && (L & (L - 1)) == 0;   // one transform = L/4 lanes: one wave, or two for L = 512
 }
 
-static size_t fft_lds(int L, int sets = 1) { return sizeof(double2) * (size_t)sets * FNP * (L + SKEW); }
-static int fft_threads(int L) { return std::max(64, FNP * (L / 4)); }
+static int fft_fzc(int L) { return L <= 256 ? 16 : 8; }
+static size_t fft_lds(int L, int sets = 1) { return sizeof(double2) * (size_t)sets * (fft_fzc(L) / 2) * (L + (L <= 256 ? 2 : 0)); }
+static int fft_threads(int L) { return std::max(64, (fft_fzc(L) / 2) * (L / 4)); }
 
 struct InvTarget {          // where an inverse ring launch writes and which unit tables it uses
     double *out;            // physical [slot][v][N] or node-space G [slot][v][NG]
@@ -322,7 +337,7 @@ struct InvTarget {          // where an inverse ring launch writes and which uni
 template <int LOGL>
 static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, const double *az, int64_t azrow) {
     const int L = 1 << LOGL;
-    dim3 g((h->nz + FZC - 1) / FZC, h->V, tg.n_units);
+    dim3 g((h->nz + fft_fzc(L) - 1) / fft_fzc(L), h->V, tg.n_units);
 #define INV_LAUNCH(NODE, ST)                                                                                                         \
     hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az,                  \
                        planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart,     \
@@ -342,7 +357,8 @@ static void launch_inv_any(sx_handle *h, const int *d_mask, const InvTarget &tg)
         case 5: launch_inv<5>(h, d_mask, tg, az, azrow); break;
         case 6: launch_inv<6>(h, d_mask, tg, az, azrow); break;
         case 7: launch_inv<7>(h, d_mask, tg, az, azrow); break;
-        default: launch_inv<8>(h, d_mask, tg, az, azrow); break;
+        case 8: launch_inv<8>(h, d_mask, tg, az, azrow); break;
+        default: launch_inv<9>(h, d_mask, tg, az, azrow); break;
     }
     HIPCHK2(hipGetLastError());
 }
@@ -375,13 +391,15 @@ void launch_node_fft(sx_handle *h) {
 void launch_fl_forward_fft(sx_handle *h) {
     const int id = timer_id(h, "k_fl_forward");
     timer_begin(h, id);
-    dim3 g((h->nz + FZC - 1) / FZC, h->V, h->nrings);
+    const int fzc = fft_fzc(h->uniform_L);
+    dim3 g((h->nz + fzc - 1) / fzc, h->V, h->nrings);
     switch (ilog2(h->uniform_L)) {
         case 4: launch_fwd<4>(h, g); break;
         case 5: launch_fwd<5>(h, g); break;
         case 6: launch_fwd<6>(h, g); break;
         case 7: launch_fwd<7>(h, g); break;
-        default: launch_fwd<8>(h, g); break;
+        case 8: launch_fwd<8>(h, g); break;
+        default: launch_fwd<9>(h, g); break;
     }
     HIPCHK2(hipGetLastError());
     timer_end(h);

@@ -785,7 +785,11 @@ template <int NZ, int CPB, class ST>
 __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
     constexpr int CS = NZ + 2;                     // column stride in LDS
     __shared__ double X[3][16 * CS];               // div, Kv*ubz, Kv*vbz   -> inputs (columns >= CPB unused)
-    __shared__ double Y[3][16 * CS];               // wb,  d/dz(...), d/dz(...) -> outputs
+    // wb, d/dz(...), d/dz(...) -> outputs.  At zDim = 128 the two tile sets would exceed the 64 KB of static LDS: the results
+    // then wait in the accumulators until every wave has finished reading X and are written over it.
+    constexpr bool ALIAS = (NZ > 64);
+    __shared__ double Ysep[ALIAS ? 1 : 3][ALIAS ? 1 : 16 * CS];
+    double (*Y)[16 * CS] = ALIAS ? X : reinterpret_cast<double (*)[16 * CS]>(&Ysep[0][0]);
     __shared__ double s1[2][16];                   // ub, vb at level 1 ("10 m")
     const int k = threadIdx.x % NZ, cl = threadIdx.x / NZ;
     const int64_t col = a.col0 + (int64_t)blockIdx.x * CPB + cl;
@@ -845,17 +849,31 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         constexpr int RT = NZ / 16;                 // row tiles per operand
         constexpr int NW = CPB * NZ / 64;           // waves in the workgroup
-        for (int job = wave; job < 3 * RT; job += NW) {
-            const int op = job / RT, rt = job % RT;
-            const double *MT = (op == 0) ? a.MintT : a.MdzT;      // MT[j][k] = M[k][j]
-            const double *xb = X[op] + (lane & 15) * CS + (lane >> 4);
-            const double *ma = MT + (int64_t)(lane >> 4) * NZ + rt * 16 + (lane & 15);
-            mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        constexpr int JPW = (3 * RT + NW - 1) / NW;  // jobs per wave
+        mfma_d4 acc[JPW];
+#pragma unroll
+        for (int jj = 0; jj < JPW; jj++) {
+            const int job = wave + jj * NW;
+            acc[jj] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+            if (job < 3 * RT) {
+                const int op = job / RT, rt = job % RT;
+                const double *MT = (op == 0) ? a.MintT : a.MdzT;      // MT[j][k] = M[k][j]
+                const double *xb = X[op] + (lane & 15) * CS + (lane >> 4);
+                const double *ma = MT + (int64_t)(lane >> 4) * NZ + rt * 16 + (lane & 15);
 #pragma unroll 4
-            for (int ks = 0; ks < NZ / 4; ks++)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[(int64_t)ks * 4 * NZ], xb[ks * 4], acc, 0, 0, 0);
-            double *yo = Y[op] + (lane & 15) * CS + rt * 16 + (lane >> 4);
-            yo[0] = acc[0]; yo[4] = acc[1]; yo[8] = acc[2]; yo[12] = acc[3];
+                for (int ks = 0; ks < NZ / 4; ks++)
+                    acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[(int64_t)ks * 4 * NZ], xb[ks * 4], acc[jj], 0, 0, 0);
+            }
+        }
+        if (ALIAS) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < JPW; jj++) {
+            const int job = wave + jj * NW;
+            if (job < 3 * RT) {
+                const int op = job / RT, rt = job % RT;
+                double *yo = Y[op] + (lane & 15) * CS + rt * 16 + (lane >> 4);
+                yo[0] = acc[jj][0]; yo[4] = acc[jj][1]; yo[8] = acc[jj][2]; yo[12] = acc[jj][3];
+            }
         }
     }
     __syncthreads();
@@ -1166,7 +1184,7 @@ template <class ST>
 static void launch_physics_t(sx_handle *h, int t) {
     if (h->eq != SX_EQ_NONE && t == 1) h->rot = 0;
     PhysArgsT<ST> a = phys_args<ST>(h, t);
-    if (h->eq == SX_EQ_ONEWAY_SW_HRBL && (h->nz == 64 || h->nz == 32)) {
+    if (h->eq == SX_EQ_ONEWAY_SW_HRBL && (h->nz == 64 || h->nz == 32 || h->nz == 128)) {
         // rings [0, R_in): ring-wise physical slots; rings [R_in, nrings): node-space transforms (node_mode only)
         const int64_t split = (h->node_mode && h->node_active) ? (int64_t)h->R_in * h->uniform_L : h->Nh;
         if (h->d_G) a.G = planes_of<ST>(h->d_G, h->V, h->NG);
@@ -1176,7 +1194,8 @@ static void launch_physics_t(sx_handle *h, int t) {
             timer_begin(h, id);
             a.col0 = 0; a.col1 = split;
             if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, PCPB, ST>), grid1(split, PCPB), dim3(PCPB * 64), 0, h->stream, a);
-            else hipLaunchKernelGGL((k_phys_hrbl_mfma<32, PCPB, ST>), grid1(split, PCPB), dim3(PCPB * 32), 0, h->stream, a);
+            else if (h->nz == 32) hipLaunchKernelGGL((k_phys_hrbl_mfma<32, PCPB, ST>), grid1(split, PCPB), dim3(PCPB * 32), 0, h->stream, a);
+            else hipLaunchKernelGGL((k_phys_hrbl_mfma<128, 8, ST>), grid1(split, 8), dim3(8 * 128), 0, h->stream, a);
             HIPCHK(hipGetLastError());
             timer_end(h);
         }

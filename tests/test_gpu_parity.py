@@ -54,16 +54,17 @@ def test_rlz_hrbl(ring_L):
     assert _run(cases.rlz_hrbl(ring_L=ring_L), 4) < TOL
 
 
-@pytest.mark.parametrize("ring_L,zDim,cells", [(256, 20, 4), (64, 16, 5), (128, 9, 4)])
+@pytest.mark.parametrize("ring_L,zDim,cells", [(256, 20, 4), (64, 16, 5), (128, 9, 4), (512, 12, 3)])
 def test_rlz_hrbl_fft_rings(ring_L, zDim, cells):
-    """Power-of-two uniform rings take the Stockham FFT kernels (incl. partial z-chunks and odd log2 L)."""
+    """Power-of-two uniform rings take the Stockham FFT kernels (incl. partial z-chunks, odd log2 L, and the 512-point
+    transform that spans two waves)."""
     assert _run(cases.rlz_hrbl(num_cells=cells, zDim=zDim, ring_L=ring_L), 3) < TOL
 
 
-@pytest.mark.parametrize("zDim", [64, 32])
+@pytest.mark.parametrize("zDim", [64, 32, 128])
 def test_rlz_hrbl_mfma_column_operators(zDim):
-    """zDim 64 / 32 take the f64-MFMA column-operator kernel (16 columns per workgroup, ragged last block) and, on
-    uniform rings, the node-space ("radial last") inverse: rings 1..6 ring-wise, rings 7..9 from node transforms."""
+    """zDim 64 / 32 / 128 take the f64-MFMA column-operator kernel (16 or 8 columns per workgroup, ragged last block)
+    and, for 64 / 32 on uniform rings, the node-space ("radial last") inverse."""
     assert _run(cases.rlz_hrbl(num_cells=3, zDim=zDim, ring_L=16), 3) < TOL
 
 
@@ -81,6 +82,20 @@ def test_node_space_inverse_equals_ring_wise_inverse(monkeypatch):
 
 def test_rl_slab_fft_rings():
     assert _run(cases.rl_slab(ring_L=64), 4) < TOL
+
+
+def test_rl_slab_512_point_rings_all_wavenumbers():
+    """90 cells x 512-point rings: kmax grows to 255, so every bin of the two-wave 512-point FFT carries signal."""
+    case = cases.rl_slab(num_cells=90, ring_L=512)
+    ref, hip = cases.OracleModel(case), cases.HipModel(case)
+    for _ in range(3):
+        ref.step()
+        hip.step()
+    a, b = hip.physical(), ref.physical()
+    assert cases.rel_err_per_var(a[:, :, :3], b[:, :, :3]) < TOL          # values, d/dr, d2/dr2: 1e-13 in practice
+    # d/dlambda, d2/dlambda2 multiply the coefficients' rounding error by k and k^2 (kmax^2 = 65,025): 1.1e-10 measured,
+    # the same in the oracle's own fp64 arithmetic (see tests/test_gpu_configs.py for the config-2 discussion)
+    assert cases.rel_err_per_var(a, b) < 1e-9
 
 
 def test_rlz_advection():
@@ -132,9 +147,12 @@ F32_TOL_VAL, F32_TOL_DER = 1e-6, 5e-5
                                        (cases.rl_slab, {"num_cells": 6, "ring_L": 32}),
                                        (cases.rlz_hrbl, {"num_cells": 4, "zDim": 12}),
                                        (cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}),
-                                       (cases.rlz_hrbl, {"num_cells": 6, "zDim": 64, "ring_L": 16})])
+                                       (cases.rlz_hrbl, {"num_cells": 6, "zDim": 64, "ring_L": 16}),
+                                       (cases.rlz_hrbl, {"num_cells": 4, "zDim": 128, "ring_L": 512})])   # config 5, cut down
 def test_fp32_storage_mode_within_declared_tolerance(maker, kw):
     case = maker(**kw)
+    if kw.get("zDim", 0) >= 128:
+        case["ts"] = 0.05      # 128 Chebyshev levels (0.3 m end spacing): the explicit vertical mixing needs a short step
     ref = cases.OracleModel(case)
     hip = cases.HipModel(case, storage="f32")
     for _ in range(3):
