@@ -16,11 +16,12 @@ def timer_name(kernel):
     k = kernel.split("(")[0].replace("void ", "").replace("sx::", "")
     base, _, targs = k.partition("<")
     targs = targs.rstrip(">").replace(" ", "").split(",") if targs else []
-    if base == "k_rl_inverse_fft":
-        return "k_node_fft" if targs[-1] in ("true", "1") else "k_rl_inverse"
-    if base == "k_phys_hrbl_mfma":           # <NZ, NODE, CPB>
-        return "k_phys_hrbl" if targs[1] in ("true", "1") else "k_phys_hrbl_inner"
-    return {"k_fl_forward_fft": "k_fl_forward", "k_colmat": "k_zinv", "k_solve_banded": "k_solve"}.get(base, base)
+    if base == "k_rl_inverse_fft":           # <LOGL, COPYOUT, NODE, ST>
+        return "k_node_fft" if targs[2] in ("true", "1") else "k_rl_inverse"
+    if base == "k_phys_hrbl_mfma":           # ring-wise HRBL kernel: the inner rings when the cell kernel takes the rest
+        return "k_phys_hrbl_inner"
+    return {"k_fl_forward_fft": "k_fl_forward", "k_colmat": "k_zinv", "k_sbw": "k_sbz",
+            "k_phys_hrbl_cell": "k_phys_hrbl"}.get(base, base)
 
 
 def load(path, name):
