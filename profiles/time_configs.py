@@ -31,7 +31,21 @@ def run(name, case, steps=50, warmup=10):
     hip.run.close()
 
 
+def config4_native_equivalent():
+    """SURVEY.md 8(d) "native-equivalent shape": 85 cells -> 255 native ragged rings (4 + 4 ri points, kmax = ri),
+    131,580 horizontal points x 64 levels, same equation set / parameters / initial condition as bench.py."""
+    import bench
+    kw, _ = bench.grid_kwargs("rlz_513x256x64")
+    kw["num_cells"] = 85
+    return dict(name="config4_native", grid=kw, eq="Oneway_ShallowWater_HeightResolvedBL", ts=bench.TS, par=dict(bench.PAR),
+                ic=bench.initial_condition)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "native4":
+        run("config 4 native-equivalent: RLZ 85 cells, native ragged rings x 64 levels (direct DFT)", config4_native_equivalent(),
+            steps=5, warmup=2)
+        sys.exit(0)
     c2 = cases.config2_literal()
     run("config 2: RL cha_bell2024 Oneway slab, 100 cells, native ragged rings (direct DFT)", c2)
     c2u = cases.config2_literal()

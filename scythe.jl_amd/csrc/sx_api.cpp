@@ -346,6 +346,8 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         for (int k = 0; k <= km; k++) ph.push_back(make_double2(std::cos(k * off), std::sin(k * off)));
     }
     h->kmax_max = h->kDim_t;
+    h->L_all_mult4 = true;
+    for (int i = 0; i < h->nrings; i++) if (h->hL[i] % 4) h->L_all_mult4 = false;
     h->K2t = 1 + 2 * h->kDim_t;
     h->Nh = pcount;
     h->N = pcount * h->nz;

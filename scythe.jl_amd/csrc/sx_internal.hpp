@@ -105,6 +105,7 @@ struct sx_handle {
     std::vector<int> a2a_cell0, a2a_ncells;
     int *d_a2a_owner = nullptr;
     int64_t *d_a2a_soff = nullptr, *d_a2a_cw = nullptr, *d_a2a_cs = nullptr, *d_a2a_offA = nullptr, *d_a2a_offB = nullptr;
+    bool L_all_mult4 = false;   // every ring length is a multiple of 4 (native rings are): the MFMA DFT kernels apply
     int f32 = 0;   // fp32 storage of d_Az, d_phys, d_G, d_Fl (allocated as raw bytes, typed by the launchers)
     double *d_Az = nullptr, *d_phys = nullptr, *d_np1 = nullptr, *d_E[3] = {}, *d_I[3] = {};
     double *d_Fl = nullptr;
@@ -147,6 +148,9 @@ namespace sx {
 void launch_zinv(sx_handle *h, bool full);
 void launch_rl_inverse(sx_handle *h, bool full);
 bool fft_path_ok(const sx_handle *h);
+bool dft_mfma_ok(const sx_handle *h);
+void launch_rl_inverse_dft(sx_handle *h, const int *d_mask);
+void launch_fl_forward_dft(sx_handle *h);
 void launch_rl_inverse_fft(sx_handle *h, const int *d_mask, int n_rings = -1);
 void launch_node_fft(sx_handle *h);
 void launch_fl_forward_fft(sx_handle *h);

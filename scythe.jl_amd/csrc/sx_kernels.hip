@@ -1139,6 +1139,7 @@ void launch_rl_inverse(sx_handle *h, bool full) {
         return;
     }
     if (fft_path_ok(h)) { launch_rl_inverse_fft(h, mask); return; }
+    if (dft_mfma_ok(h)) { launch_rl_inverse_dft(h, mask); return; }
     const int id = timer_id(h, "k_rl_inverse");
     timer_begin(h, id);
     const int cstride = (h->kmax_max + 1) | 1;
@@ -1256,6 +1257,7 @@ void launch_physics(sx_handle *h, int t) {
 
 void launch_fl_forward(sx_handle *h) {
     if (fft_path_ok(h)) { launch_fl_forward_fft(h); return; }
+    if (dft_mfma_ok(h)) { launch_fl_forward_dft(h); return; }
     const int id = timer_id(h, "k_fl_forward");
     timer_begin(h, id);
     const int xstride = h->L_max | 1;
