@@ -43,8 +43,8 @@ def config4_native_equivalent():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "native4":
-        run("config 4 native-equivalent: RLZ 85 cells, native ragged rings x 64 levels (direct DFT)", config4_native_equivalent(),
-            steps=5, warmup=2)
+        run("config 4 native-equivalent: RLZ 85 cells, native ragged rings x 64 levels (matrix-core DFT)",
+            config4_native_equivalent(), steps=10, warmup=3)
         sys.exit(0)
     c2 = cases.config2_literal()
     run("config 2: RL cha_bell2024 Oneway slab, 100 cells, native ragged rings (direct DFT)", c2)
@@ -53,3 +53,5 @@ if __name__ == "__main__":
     run("config 2 on uniform 256-point rings (FFT path)", c2u)
     run("config 3: RZ 513 x 128, LinearAcousticRZ + semi-implicit adjustment", cases.config3_rz())
     run("config 1: R grid LinearAdvection1D, 100 cells (plumbing)", cases.kat_r())
+    run("config 4 native-equivalent: RLZ 85 cells, native ragged rings x 64 levels (matrix-core DFT)",
+        config4_native_equivalent(), steps=10, warmup=3)
