@@ -145,6 +145,16 @@ int sx_set_patch_spectral_b(sx_handle *h, const double *shared);
 int sx_get_patch_spectral_a(sx_handle *h, double *out);
 int sx_set_patch_spectral_a(sx_handle *h, const double *a);
 
+/* --- restart state (the reference can only restart from a physical_out CSV, which loses the
+ * Adams-Bashforth history; this blob lets a run continue bit-identically) ------------------------------------------- */
+/* The tile's A coefficients (its own radial nodes) and the tendency history expdot_nm1 / expdot_nm2 (and impdot_nm1 / nm2
+ * when semi-implicit) as of the last completed step, in the library's device layout: an opaque blob for a handle created
+ * from the same descriptors.  n_doubles from sx_state_size; sx_set_state must be followed by sx_advance(h, t + 1) with the
+ * t of the step the state was taken after (t >= 2; earlier steps have no full history and restart from the values). */
+int sx_state_size(const sx_handle *h, int64_t *n_doubles);
+int sx_get_state(sx_handle *h, double *out);
+int sx_set_state(sx_handle *h, const double *in);
+
 /* --- the hot path -------------------------------------------------------------------------------------------------- */
 /* spectralTransform!(tile) on var_np1 (calcTendency, src/semiimplicit.jl:728-735) -> tile B coefficients */
 int sx_spectral_transform(sx_handle *h);
@@ -160,6 +170,9 @@ int sx_physics(sx_handle *h, int32_t t);
 /* checkCFL (src/semiimplicit.jl:737-751): flag = 1 if any NaN in the model state (scans var_np1, which every
  * sx_advance / sx_set_physical_values leaves complete; a NaN in physical[:, v, 1] always reaches it) */
 int sx_check_nan(sx_handle *h, int32_t *flag);
+/* on-device diagnostic: out[n_vars] = max |var_np1[:, v]| after the last step; with the grid spacing
+ * the caller forms the advective CFL number without pulling a field to the host (NaNs are skipped: see sx_check_nan) */
+int sx_max_abs(sx_handle *h, double *out);
 
 /* --- tile <-> patch exchange on the device (src/semiimplicit.jl:320-329, 272-285) ---------------------------------- */
 /* The tile's B coefficients live in a [tile_b_rDim][n_cols] row-major device array (row = radial node).

@@ -55,6 +55,9 @@ SYMBOLS = {
     "sx_set_physical_values": (C.c_int, [_H, P_D]),
     "sx_get_physical": (C.c_int, [_H, P_D]),
     "sx_get_var_np1": (C.c_int, [_H, P_D]),
+    "sx_state_size": (C.c_int, [_H, P_I64]),
+    "sx_get_state": (C.c_int, [_H, P_D]),
+    "sx_set_state": (C.c_int, [_H, P_D]),
     "sx_get_tile_spectral": (C.c_int, [_H, P_D]),
     "sx_set_patch_spectral_b": (C.c_int, [_H, P_D]),
     "sx_get_patch_spectral_a": (C.c_int, [_H, P_D]),
@@ -65,6 +68,7 @@ SYMBOLS = {
     "sx_advance": (C.c_int, [_H, C.c_int32]),
     "sx_physics": (C.c_int, [_H, C.c_int32]),
     "sx_check_nan": (C.c_int, [_H, P_I32]),
+    "sx_max_abs": (C.c_int, [_H, P_D]),
     "sx_tile_b_device": (C.c_int, [_H, C.POINTER(C.c_void_p), P_I64, P_I64]),
     "sx_bind_tile_b": (C.c_int, [_H, C.c_void_p]),
     "sx_halo_add": (C.c_int, [_H, C.c_void_p]),

@@ -657,6 +657,55 @@ int sx_get_var_np1(sx_handle *h, double *out) {
     return status();
 }
 
+// restart blob: [header 4 doubles: magic, nbt * C, V * N, semi][A rows of the tile][E_nm1][E_nm2]([I_nm1][I_nm2])
+static const double SX_STATE_MAGIC = 5.3171e7;
+
+int sx_state_size(const sx_handle *h, int64_t *n_doubles) {
+    clear_error();
+    if (!h || !n_doubles) { set_error("null argument"); return 1; }
+    *n_doubles = 4 + (int64_t)h->nbt * h->C + (int64_t)(h->semi ? 4 : 2) * h->V * h->N;
+    return 0;
+}
+
+int sx_get_state(sx_handle *h, double *out) {
+    clear_error();
+    if (!h || !out) { set_error("null argument"); return 1; }
+    const size_t na = (size_t)h->nbt * h->C, nv = (size_t)h->V * h->N;
+    out[0] = SX_STATE_MAGIC; out[1] = (double)na; out[2] = (double)nv; out[3] = h->semi ? 1.0 : 0.0;
+    double *p = out + 4;
+    HIPOK(hipMemcpyAsync(p, h->d_A + (int64_t)h->cell0 * h->C, sizeof(double) * na, hipMemcpyDeviceToHost, h->stream));
+    p += na;
+    // after a step the buffer written as expdot_n has become nm1: E1 = d_E[(rot + 1) % 3], E2 = d_E[(rot + 2) % 3]
+    for (int q = 1; q <= 2; q++, p += nv)
+        HIPOK(hipMemcpyAsync(p, h->d_E[(h->rot + q) % 3], sizeof(double) * nv, hipMemcpyDeviceToHost, h->stream));
+    if (h->semi)
+        for (int q = 1; q <= 2; q++, p += nv)
+            HIPOK(hipMemcpyAsync(p, h->d_I[(h->rot + q) % 3], sizeof(double) * nv, hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    return status();
+}
+
+int sx_set_state(sx_handle *h, const double *in) {
+    clear_error();
+    if (!h || !in) { set_error("null argument"); return 1; }
+    const size_t na = (size_t)h->nbt * h->C, nv = (size_t)h->V * h->N;
+    if (in[0] != SX_STATE_MAGIC || in[1] != (double)na || in[2] != (double)nv || in[3] != (h->semi ? 1.0 : 0.0)) {
+        set_error("sx_set_state: the blob does not belong to a handle with these dimensions");
+        return 1;
+    }
+    const double *p = in + 4;
+    HIPOK(hipMemcpyAsync(h->d_A + (int64_t)h->cell0 * h->C, p, sizeof(double) * na, hipMemcpyHostToDevice, h->stream));
+    p += na;
+    h->rot = 0;
+    for (int q = 1; q <= 2; q++, p += nv)
+        HIPOK(hipMemcpyAsync(h->d_E[q], p, sizeof(double) * nv, hipMemcpyHostToDevice, h->stream));
+    if (h->semi)
+        for (int q = 1; q <= 2; q++, p += nv)
+            HIPOK(hipMemcpyAsync(h->d_I[q], p, sizeof(double) * nv, hipMemcpyHostToDevice, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
+    return status();
+}
+
 int sx_get_tile_spectral(sx_handle *h, double *out) {
     clear_error();
     if (!h || !out) { set_error("null argument"); return 1; }
@@ -765,6 +814,21 @@ int sx_check_nan(sx_handle *h, int32_t *flag) {
     HIPOK(hipMemcpyAsync(&f, h->d_flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPOK(hipStreamSynchronize(h->stream));
     *flag = f;
+    return status();
+}
+
+int sx_max_abs(sx_handle *h, double *out) {
+    clear_error();
+    if (!h || !out) { set_error("null argument"); return 1; }
+    unsigned long long *d = nullptr;
+    HIPOK(hipMalloc(&d, sizeof(unsigned long long) * h->V));
+    launch_max_abs(h, d);
+    std::vector<unsigned long long> bits(h->V);
+    hipError_t e = hipMemcpyAsync(bits.data(), d, sizeof(unsigned long long) * h->V, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d);
+    if (e != hipSuccess) { set_error(std::string("sx_max_abs: ") + hipGetErrorString(e)); return 1; }
+    for (int v = 0; v < h->V; v++) std::memcpy(&out[v], &bits[v], sizeof(double));
     return status();
 }
 

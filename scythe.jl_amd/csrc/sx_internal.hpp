@@ -164,6 +164,7 @@ void launch_solve_a2a(sx_handle *h, const double *recv, double *send);
 void launch_a2a_pack(sx_handle *h, double *buf, int unpack);
 void launch_halo_add(sx_handle *h, const double *recv);
 void launch_nan_check(sx_handle *h);
+void launch_max_abs(sx_handle *h, unsigned long long *d_out);
 int timer_id(sx_handle *h, const char *name);
 void timer_begin(sx_handle *h, int id);
 void timer_end(sx_handle *h);

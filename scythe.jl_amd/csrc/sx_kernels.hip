@@ -570,6 +570,22 @@ __global__ void k_nan_check(const double *__restrict__ x, int64_t n, int *flag) 
     if (bad) atomicOr(flag, 1);
 }
 
+// max |x[v][p]| per variable: the bit pattern of a non-negative double orders like an unsigned integer
+__global__ void k_max_abs(const double *__restrict__ x, int64_t N, unsigned long long *__restrict__ out) {
+    const int v = blockIdx.y;
+    const double *xv = x + (int64_t)v * N;
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a = fabs(xv[i]);
+        if (a > m) m = a;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double t = __shfl_xor(m, o);
+        if (t > m) m = t;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out + v, (unsigned long long)__double_as_longlong(m));
+}
+
 // ------------------------------------------------------------------------------------------------ equation sets
 template <class ST>
 struct PhysArgsT {
@@ -1356,6 +1372,12 @@ void launch_halo_add(sx_handle *h, const double *recv) {
     hipLaunchKernelGGL(k_halo_add, grid1(n, 256), dim3(256), 0, h->stream, h->d_Btile, recv, n);
     HIPCHK(hipGetLastError());
     timer_end(h);
+}
+
+void launch_max_abs(sx_handle *h, unsigned long long *d_out) {
+    HIPCHK(hipMemsetAsync(d_out, 0, sizeof(unsigned long long) * h->V, h->stream));
+    hipLaunchKernelGGL(k_max_abs, dim3(512, h->V), dim3(256), 0, h->stream, h->d_np1, h->N, d_out);
+    HIPCHK(hipGetLastError());
 }
 
 void launch_nan_check(sx_handle *h) {

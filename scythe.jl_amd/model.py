@@ -262,6 +262,18 @@ class Grid:
         L.check(self._lib.sx_get_physical(self._h, out.ctypes.data_as(L.P_D)))
         return out
 
+    def get_state(self):
+        """Restart blob of this tile (A coefficients + Adams-Bashforth history), see sx_get_state."""
+        n = C.c_int64(0)
+        L.check(self._lib.sx_state_size(self._h, C.byref(n)))
+        out = np.zeros(n.value)
+        L.check(self._lib.sx_get_state(self._h, out.ctypes.data_as(L.P_D)))
+        return out
+
+    def set_state(self, blob):
+        b = np.ascontiguousarray(blob, dtype=np.float64)
+        L.check(self._lib.sx_set_state(self._h, b.ctypes.data_as(L.P_D)))
+
     @property
     def var_np1(self):
         out = np.zeros((self.N, self.V), order="F")
@@ -306,6 +318,12 @@ class Grid:
 
     def physics(self, t):
         L.check(self._lib.sx_physics(self._h, int(t)))
+
+    def max_abs(self):
+        """max |var_np1[:, v]| per variable, reduced on the device (sx_max_abs)."""
+        out = np.zeros(self.V)
+        L.check(self._lib.sx_max_abs(self._h, out.ctypes.data_as(L.P_D)))
+        return out
 
     def check_nan(self):
         f = C.c_int32(0)

@@ -174,3 +174,31 @@ def test_fp32_storage_mode_within_declared_tolerance(maker, kw):
     err_all = cases.rel_err_per_var(a, b)
     assert err_val < F32_TOL_VAL, err_val
     assert 1e-9 < err_all < F32_TOL_DER, err_all      # the lower bound proves the fp32 path really ran
+
+
+@pytest.mark.parametrize("maker,kw,ntiles", [(cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}, 1),
+                                             (cases.rz_semiimplicit, {}, 1),
+                                             (cases.rl_slab, {"num_cells": 9}, 3)])
+def test_checkpoint_restart_continues_bit_identically(tmp_path, maker, kw, ntiles):
+    """save_checkpoint after step 5 -> a fresh run that loads it continues exactly like the uninterrupted one."""
+    case = maker(**kw)
+    a = cases.HipModel(case, num_tiles=ntiles)
+    for _ in range(5):
+        a.step()
+    ck = str(tmp_path / "ck.npz")
+    a.run.save_checkpoint(ck)
+    for _ in range(4):
+        a.step()
+    b = cases.HipModel(case, num_tiles=ntiles)
+    b.run.load_checkpoint(ck)
+    assert b.run.t == 5
+    for _ in range(4):
+        b.step()
+    assert np.array_equal(a.physical(), b.physical())
+
+
+def test_max_abs_diagnostic_matches_host_reduction():
+    m = cases.HipModel(cases.rlz_hrbl(num_cells=5, zDim=10))
+    m.step()
+    g = m.run.tiles[0]
+    assert np.array_equal(g.max_abs(), np.abs(g.var_np1).max(axis=0))
