@@ -257,6 +257,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->rDim = MUBAR * h->nc; h->b_rDim = h->nc + 3;
     h->uniform_L = h->has_l ? g->ring_uniform_L : 0;
     h->f32 = g->storage_f32 ? 1 : 0;
+    h->overlap = getenv("SX_OVERLAP") && atoi(getenv("SX_OVERLAP")) != 0;
     h->cell0 = g->tile_cell0; h->ncells = g->tile_num_cells; h->tile_num = g->tile_num;
     h->nrings = MUBAR * h->ncells; h->nbt = h->ncells + 3;
     for (int i = 0; i < 7; i++) h->slot[i] = DERIV_SLOTS[h->geom][i];
@@ -568,6 +569,9 @@ int sx_destroy(sx_handle *h) {
     hipDeviceSynchronize();
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->event_pool) hipEventDestroy(e);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->stream2) hipStreamDestroy(h->stream2);
     for (void *p : h->allocs) hipFree(p);
     delete h;
     return 0;
@@ -798,8 +802,7 @@ int sx_advance(sx_handle *h, int32_t t) {
     if (!h) { set_error("null handle"); return 1; }
     if (t < 1) { set_error("t is 1-based"); return 1; }
     launch_zinv(h, false);
-    launch_rl_inverse(h, false);
-    launch_physics(h, t);
+    launch_inverse_and_physics(h, t);
     launch_fl_forward(h);
     launch_sb(h);
     launch_zf(h);

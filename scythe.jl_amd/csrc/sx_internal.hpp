@@ -105,6 +105,11 @@ struct sx_handle {
     std::vector<int> a2a_cell0, a2a_ncells;
     int *d_a2a_owner = nullptr;
     int64_t *d_a2a_soff = nullptr, *d_a2a_cw = nullptr, *d_a2a_cs = nullptr, *d_a2a_offA = nullptr, *d_a2a_offB = nullptr;
+    // second stream for the inner-ring chain of sx_advance (launch_inverse_and_physics); off unless SX_OVERLAP=1: measured
+    // +2.6 % (669 vs 653 steps/s) - the two chains compete for the same HBM bandwidth - and it blurs the per-kernel timers
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int overlap = 0;
     bool L_all_mult4 = false;   // every ring length is a multiple of 4 (native rings are): the MFMA DFT kernels apply
     int f32 = 0;   // fp32 storage of d_Az, d_phys, d_G, d_Fl (allocated as raw bytes, typed by the launchers)
     double *d_Az = nullptr, *d_phys = nullptr, *d_np1 = nullptr, *d_E[3] = {}, *d_I[3] = {};
@@ -155,6 +160,7 @@ void launch_rl_inverse_fft(sx_handle *h, const int *d_mask, int n_rings = -1);
 void launch_node_fft(sx_handle *h);
 void launch_fl_forward_fft(sx_handle *h);
 void launch_physics(sx_handle *h, int t);
+void launch_inverse_and_physics(sx_handle *h, int t);
 void launch_copy_slot0(sx_handle *h);
 void launch_fl_forward(sx_handle *h);
 void launch_sb(sx_handle *h);
