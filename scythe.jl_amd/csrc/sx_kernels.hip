@@ -963,8 +963,8 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     const int64_t pc = ((int64_t)(cell * MUBAR) * a.L + lam) * NZ + k;      // ring mu = 0; + mu * L * NZ for the others
 #define HIST(mu)                                                                                   \
     _Pragma("unroll") for (int v = 0; v < 5; v++) {                                                \
-        e1h[mu][v] = (a.t >= 2) ? a.E1[(int64_t)v * a.N + pc + (mu) * gs] : 0.0;                   \
-        e2h[mu][v] = (a.t >= 3) ? a.E2[(int64_t)v * a.N + pc + (mu) * gs] : 0.0;                   \
+        e1h[mu][v] = (a.t >= 2) ? __builtin_nontemporal_load(a.E1 + (int64_t)v * a.N + pc + (mu) * gs) : 0.0;   \
+        e2h[mu][v] = (a.t >= 3) ? __builtin_nontemporal_load(a.E2 + (int64_t)v * a.N + pc + (mu) * gs) : 0.0;   \
     }
     HIST(0)
 #define DOT(w, q) ((w)[0] * q[0] + (w)[1] * q[1] + (w)[2] * q[2] + (w)[3] * q[3])
@@ -1055,7 +1055,7 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
 #pragma unroll
         for (int v = 0; v < 5; v++) {          // explicit_timestep (src/semiimplicit.jl:672-698)
             const int64_t o = (int64_t)v * a.N + p;
-            a.En[o] = ee[v];
+            __builtin_nontemporal_store(ee[v], a.En + o);      // read again only by the next step
             double un;
             if (a.t == 1) un = uu[v] + (a.ts * ee[v]);
             else if (a.t == 2) un = uu[v] + (0.5 * a.ts) * ((3.0 * ee[v]) - e1h[mu][v]);
