@@ -48,6 +48,8 @@ enum {
     SX_EQ_LINEAR_ACOUSTIC_RZ = 7,    /* synthetic vehicle for semiimplicit_adjustment (src/semiimplicit.jl:521-597);
                                         Euler_test's variable layout and implicit terms (src/testModels.jl:188-205)
                                         with a linearised pressure-gradient force */
+    SX_EQ_EULER_TEST = 8,            /* src/testModels.jl:100-215: moist Euler RZ (s, xi, mu, u, w) about a reference state,
+                                        semi-implicit in the vertical acoustic terms; needs sx_model_desc.ref_state */
     SX_EQ_NONE = 99                  /* transforms only: sx_advance copies physical[:, :, 1] into var_np1 */
 };
 
@@ -92,6 +94,9 @@ typedef struct sx_model_desc {
     int32_t w_index, xi_index;/* 1-based variable indices of "w" and "xi" (semi-implicit only), 0 = absent */
     int32_t col_var;          /* 1-based variable whose vertical BCs the column operators of HRBL use ("h",
                                  src/shallowWaterModels.jl:423), 0 = variable 1 */
+    const double *ref_state;  /* ReferenceState (src/reference_state.jl:4-10) for Euler_test, or NULL:
+                                 [3][3][zDim] = (sbar, xibar, mubar) x (value, d/dz, d2/dz2) x level (0 = bottom);
+                                 Pxi_bar travels in params[SX_P_PXI_BAR] */
 } sx_model_desc;
 
 typedef struct sx_dims {
@@ -129,6 +134,13 @@ int sx_get_gridpoints(const sx_handle *h, double *out);
 /* calcTileSizes(patch, n) (src/semiimplicit.jl:141): out[5, n] column-major rows = xmin, xmax, num_cells,
  * spectralIndexL, gridpoint count.  Pure host helper, no handle needed. */
 int sx_calc_tile_sizes(const sx_grid_desc *patch, int32_t n_tiles, double *out);
+
+/* Chebyshev column operators (Springsteel CBtransform! -> CAtransform! -> CItransform! / CIxtransform / CIxxtransform /
+ * CIInttransform(C0 = 0); call sites src/reference_state.jl:95-117, 143-167, src/shallowWaterModels.jl:426-429) as dense
+ * [zDim x zDim] row-major collocation matrices acting on the values of one column (index 0 = bottom), and the levels z.
+ * Pure host helper for one-time set-up work such as the reference state; any output pointer may be NULL. */
+int sx_cheb_column_ops(double zmin, double zmax, int32_t zDim, int32_t b_zDim, int32_t bcb, int32_t bct, double *z,
+                       double *rec, double *dz, double *dzz, double *integ);
 
 /* --- state in / out (host pointers, reference layouts) ------------------------------------------------------------- */
 /* read_physical_grid -> physical[:, v, 1]  (src/semiimplicit.jl:134): values[n_points, n_vars] */

@@ -501,6 +501,54 @@ def semi_matrices(ch, pxi_bar, tau):
     return np.asarray(ch._x["T"] @ Hinv, dtype=np.float64), np.asarray(ch._x["TD"] @ Hinv, dtype=np.float64)
 
 
+# ----------------------------------------------------------------------------- moist thermodynamics (Euler_test)
+# Restated from src/thermodynamics.jl (constants :2-17, :31-32): only what Euler_test (src/testModels.jl:100-215) calls.
+TH = dict(Rd=287.04, Rv=461.50, Cvd=716.96, Cvv=1410.0, Cl=4186.0, gravity=9.81, L_v0=2.501e6, T_0=273.16, p_0=1000.0, q0=1.0e-7)
+TH["Cpv"] = TH["Cvv"] + TH["Rv"]
+TH["rho_d0"] = 100.0 * TH["p_0"] / (TH["T_0"] * TH["Rd"])
+TH["rho_v0"] = 100.0 * (6.112 * np.exp(17.67 * (TH["T_0"] - 273.15) / ((TH["T_0"] - 273.15) + 243.5))) / (TH["T_0"] * TH["Rv"])
+
+
+def th_ahyp(mu):                                       # src/thermodynamics.jl:190-198
+    q0 = TH["q0"]
+    return np.where(mu < 0.0, 0.0, np.sqrt(mu * mu + q0 * q0) + mu - q0)
+
+
+def th_dmudq(mu, q_v):                                 # :200-203
+    return ((q_v + TH["q0"]) - mu) / (q_v + TH["q0"])
+
+
+def th_dry_density(xi):                                # :205-208
+    return TH["rho_d0"] * np.exp(xi)
+
+
+def th_temperature(s, rho_d, q_v):                     # :67-80  (L_v(T_0) = L_v0, :41-44)
+    Cf = TH["Cvd"] + (q_v * TH["Cvv"])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        qf = np.where(q_v != 0.0, (rho_d * q_v / TH["rho_v0"]) ** ((q_v * TH["Rv"]) / Cf), 1.0)
+    rf = (rho_d / TH["rho_d0"]) ** (TH["Rd"] / Cf)
+    Tf = np.exp((s - (q_v * TH["L_v0"] / TH["T_0"])) / Cf)
+    return TH["T_0"] * Tf * rf * qf
+
+
+def th_P_s(Tk, rho_d, q_v):                            # :215-219
+    return Tk * ((rho_d * TH["Rd"]) + (q_v * rho_d * TH["Rv"])) / (TH["Cvd"] + (q_v * TH["Cvv"]))
+
+
+def th_P_xi(Tk, rho_d, q_v):                           # :221-224
+    return (TH["Rd"] + (q_v * rho_d * TH["Rv"])) * ((rho_d * Tk) + th_P_s(Tk, rho_d, q_v))
+
+
+def th_P_qv(Tk, rho_d, q_v):                           # :232-242
+    with np.errstate(divide="ignore", invalid="ignore"):
+        qf = TH["Rv"] * (1 + np.log(q_v * rho_d / TH["rho_v0"])) - (TH["Cvv"] * np.log(Tk / TH["T_0"])) - TH["L_v0"] / TH["T_0"]
+    return np.where(q_v != 0.0, (rho_d * TH["Rv"] * Tk) + qf * th_P_s(Tk, rho_d, q_v), 0.0)
+
+
+def th_pressure_gradient(Tk, rho_d, q_v, s_x, xi_x, qv_x):     # :250-258
+    return (th_P_s(Tk, rho_d, q_v) * s_x) + (th_P_xi(Tk, rho_d, q_v) * xi_x) + (th_P_qv(Tk, rho_d, q_v) * qv_x)
+
+
 def tendency(grid, eq, par, phys, pts, col_ops=None):
     """Pointwise tendencies of the in-scope equation sets. phys [N,V,D]; returns (expdot [N,V], impdot [N,V] or None, phys)
     (phys is returned because the shallow-water sets overwrite the diagnostic w in slot 1)."""
@@ -595,6 +643,35 @@ def tendency(grid, eq, par, phys, pts, col_ops=None):
         E[:, 2] = adv(3) + dif(3)
         E[:, 3] = adv(4) + (-(pxi * P(2, "r"))) + dif(4)
         E[:, 4] = adv(5) + (-(pxi * P(2, "z"))) + dif(5)
+        I[:, 4] = -(pxi * P(2, "z"))
+    elif eq == "Euler_test":                            # src/testModels.jl:100-215
+        # par["ref_state"] = dict(sbar, xibar, mubar: [zDim, 3] value / d/dz / d2/dz2 per level; ReferenceState,
+        # src/reference_state.jl:4-10); Pxi_bar in par.  The reference indexes the [zDim] profiles with the column's points
+        # (z fastest), i.e. level k of every column sees row k.
+        K, pxi, rs = par["K"], par["Pxi_bar"], par["ref_state"]
+        nz = grid.zDim
+        lev = np.arange(N) % nz
+        sbar_z, xibar, xibar_z = rs["sbar"][lev, 1], rs["xibar"][lev, 0], rs["xibar"][lev, 1]
+        sbar, mubar, mubar_z = rs["sbar"][lev, 0], rs["mubar"][lev, 0], rs["mubar"][lev, 1]
+        u, w = P(4, "u"), P(5, "u")
+        q_v = th_ahyp(P(3, "u") + mubar)
+        rho_d = th_dry_density(P(2, "u") + xibar)
+        Tk = th_temperature(P(1, "u") + sbar, rho_d, q_v)
+        rho_t = rho_d * (1.0 + q_v)
+        dm = th_dmudq(P(3, "u") + mubar, q_v)
+        qvp_x, qvp_z = P(3, "r") / dm, P(3, "z") / dm
+        rhobar = th_dry_density(xibar) * (1.0 + th_ahyp(mubar))
+        rho_p = rho_t - rhobar
+        dif = lambda v: K * (P(v, "rr") + P(v, "zz"))
+        I = np.zeros((N, grid.V))
+        E[:, 0] = ((-u * P(1, "r")) + (-w * (P(1, "z") + sbar_z))) + dif(1)
+        E[:, 1] = ((-u * P(2, "r")) + (-w * (P(2, "z") + xibar_z))) - P(4, "r") - P(5, "z")
+        I[:, 1] = -P(5, "z")
+        E[:, 2] = ((-u * P(3, "r")) + (-w * (P(3, "z") + mubar_z))) + dif(3)
+        E[:, 3] = ((-u * P(4, "r")) + (-w * P(4, "z"))) + \
+                  (-(th_pressure_gradient(Tk, rho_d, q_v, P(1, "r"), P(2, "r"), qvp_x) / rho_t)) + dif(4)
+        E[:, 4] = ((-u * P(5, "r")) + (-w * P(5, "z"))) + \
+                  (-(TH["gravity"] * rho_p / rho_t) - (th_pressure_gradient(Tk, rho_d, q_v, P(1, "z"), P(2, "z"), qvp_z) / rho_t)) + dif(5)
         I[:, 4] = -(pxi * P(2, "z"))
     else:
         raise ValueError("equation set not in scope: " + eq)

@@ -7,3 +7,5 @@ from .model import (CubicBSpline, Chebyshev, GridParameters, ModelParameters, Gr
 from .driver import (PatchLayout, LocalExchange, DistExchange, A2ALayout, LocalA2AExchange, DistA2AExchange, ModelRun,
                      integrate_model)
 from .io import read_physical_grid, write_output
+from . import thermodynamics, reference_state
+from .reference_state import ReferenceState, Chebyshev1D

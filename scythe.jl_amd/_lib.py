@@ -28,7 +28,7 @@ class GridDesc(C.Structure):
 
 class ModelDesc(C.Structure):
     _fields_ = [("ts", C.c_double), ("equation_set", C.c_int32), ("semiimplicit", C.c_int32), ("params", P_D),
-                ("w_index", C.c_int32), ("xi_index", C.c_int32), ("col_var", C.c_int32)]
+                ("w_index", C.c_int32), ("xi_index", C.c_int32), ("col_var", C.c_int32), ("ref_state", P_D)]
 
 
 class Dims(C.Structure):
@@ -55,6 +55,7 @@ SYMBOLS = {
     "sx_set_physical_values": (C.c_int, [_H, P_D]),
     "sx_get_physical": (C.c_int, [_H, P_D]),
     "sx_get_var_np1": (C.c_int, [_H, P_D]),
+    "sx_cheb_column_ops": (C.c_int, [C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P_D, P_D, P_D, P_D, P_D]),
     "sx_state_size": (C.c_int, [_H, P_I64]),
     "sx_get_state": (C.c_int, [_H, P_D]),
     "sx_set_state": (C.c_int, [_H, P_D]),

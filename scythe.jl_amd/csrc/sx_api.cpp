@@ -159,6 +159,7 @@ int sx_equation_set_id(const char *name) {
         {"Twoway_ShallowWater_Slab", SX_EQ_TWOWAY_SW_SLAB},
         {"Oneway_ShallowWater_HeightResolvedBL", SX_EQ_ONEWAY_SW_HRBL},
         {"LinearAcousticRZ", SX_EQ_LINEAR_ACOUSTIC_RZ},
+        {"Euler_test", SX_EQ_EULER_TEST},
         {"None", SX_EQ_NONE},
     };
     if (!name) return -1;
@@ -287,12 +288,12 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     {
         const int eq = h->eq;
         const int need_geom = (eq == SX_EQ_LINEAR_ADVECTION_1D) ? SX_GEOM_R
-                            : (eq == SX_EQ_LINEAR_ADVECTION_RZ || eq == SX_EQ_LINEAR_ACOUSTIC_RZ) ? SX_GEOM_RZ
+                            : (eq == SX_EQ_LINEAR_ADVECTION_RZ || eq == SX_EQ_LINEAR_ACOUSTIC_RZ || eq == SX_EQ_EULER_TEST) ? SX_GEOM_RZ
                             : (eq == SX_EQ_LINEAR_ADVECTION_RL || eq == SX_EQ_ONEWAY_SW_SLAB || eq == SX_EQ_TWOWAY_SW_SLAB) ? SX_GEOM_RL
                             : (eq == SX_EQ_LINEAR_ADVECTION_RLZ || eq == SX_EQ_ONEWAY_SW_HRBL) ? SX_GEOM_RLZ : -1;
         const int need_vars = (eq == SX_EQ_LINEAR_ADVECTION_RZ) ? 4 : (eq == SX_EQ_LINEAR_ADVECTION_RL || eq == SX_EQ_LINEAR_ADVECTION_RLZ) ? 3
                             : (eq == SX_EQ_ONEWAY_SW_SLAB || eq == SX_EQ_TWOWAY_SW_SLAB || eq == SX_EQ_ONEWAY_SW_HRBL) ? 6
-                            : (eq == SX_EQ_LINEAR_ACOUSTIC_RZ) ? 5 : 1;
+                            : (eq == SX_EQ_LINEAR_ACOUSTIC_RZ || eq == SX_EQ_EULER_TEST) ? 5 : 1;
         if (eq != SX_EQ_NONE && need_geom < 0) { set_error("equation set not in scope"); delete h; return 1; }
         if (eq != SX_EQ_NONE && (need_geom != h->geom || h->V < need_vars)) {
             set_error("equation set does not match the grid geometry / variable count");
@@ -449,6 +450,12 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         if (!upload(h, &h->d_z, one)) FAIL();
     }
 
+    if (h->eq == SX_EQ_EULER_TEST) {
+        if (!m->ref_state) { set_error("Euler_test needs sx_model_desc.ref_state (ReferenceState)"); FAIL(); }
+        std::vector<double> ref(m->ref_state, m->ref_state + (size_t)9 * h->nz);
+        if (!upload(h, &h->d_ref, ref)) FAIL();
+    }
+
     // ---- state
     const int64_t C = h->C, N = h->N;
     if (!dalloc(h, &h->d_A, (size_t)h->b_rDim * C) || !dalloc(h, &h->d_Bfull, (size_t)h->b_rDim * C) ||
@@ -483,7 +490,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
                 eq[3] = eq[4] = u | r | rr | l | ll | (h->eq == SX_EQ_ONEWAY_SW_HRBL ? z : 0);
                 eq[5] = 0;        // w is diagnostic: written by the equation set before it is read
                 break;
-            case SX_EQ_LINEAR_ACOUSTIC_RZ:
+            case SX_EQ_LINEAR_ACOUSTIC_RZ: case SX_EQ_EULER_TEST:
                 eq[0] = eq[2] = eq[3] = eq[4] = u | r | rr | z | zz;
                 eq[1] = u | r | z;
                 break;
@@ -574,6 +581,23 @@ int sx_destroy(sx_handle *h) {
     if (h->stream2) hipStreamDestroy(h->stream2);
     for (void *p : h->allocs) hipFree(p);
     delete h;
+    return 0;
+}
+
+int sx_cheb_column_ops(double zmin, double zmax, int32_t zDim, int32_t b_zDim, int32_t bcb, int32_t bct, double *z,
+                       double *rec, double *dz, double *dzz, double *integ) {
+    clear_error();
+    if (zDim < 2 || !(zmax > zmin)) { set_error("sx_cheb_column_ops: need zDim >= 2 and zmax > zmin"); return 1; }
+    const int Zb = b_zDim > 0 ? std::min(b_zDim, zDim) : std::min(zDim, (2 * zDim - 1) / 3 + 1);
+    ChebOps o;
+    std::string err;
+    if (!build_cheb_ops(zmin, zmax, zDim, Zb, bcb, bct, o, err)) { set_error(err); return 1; }
+    const size_t n2 = (size_t)zDim * zDim;
+    if (z) std::copy(o.z.begin(), o.z.end(), z);
+    if (rec) std::copy(o.Mrec.begin(), o.Mrec.begin() + n2, rec);
+    if (dz) std::copy(o.Mdz.begin(), o.Mdz.begin() + n2, dz);
+    if (dzz) std::copy(o.Mdzz.begin(), o.Mdzz.begin() + n2, dzz);
+    if (integ) std::copy(o.Mint.begin(), o.Mint.begin() + n2, integ);
     return 0;
 }
 

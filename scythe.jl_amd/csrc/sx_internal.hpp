@@ -31,6 +31,7 @@ struct ChebOps {
     std::vector<double> Mint;    // [nz][nz]  values -> (CB, CA, CIInt) integral from the bottom
     std::vector<double> Mdz;     // [nz][nz]  values -> (CB, CA, CIx) truncated derivative
     std::vector<double> Mrec;    // [nz][nz]  values -> (CB, CA, CI) truncated reconstruction
+    std::vector<double> Mdzz;    // [nz][nz]  values -> (CB, CA, CIxx) truncated second derivative
 };
 
 void basis_tables(double DX, double phi[4][MUBAR][4]);
@@ -111,6 +112,7 @@ struct sx_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 0;
     bool L_all_mult4 = false;   // every ring length is a multiple of 4 (native rings are): the MFMA DFT kernels apply
+    double *d_ref = nullptr;    // ReferenceState [3][3][nz] (Euler_test)
     int f32 = 0;   // fp32 storage of d_Az, d_phys, d_G, d_Fl (allocated as raw bytes, typed by the launchers)
     double *d_Az = nullptr, *d_phys = nullptr, *d_np1 = nullptr, *d_E[3] = {}, *d_I[3] = {};
     double *d_Fl = nullptr;

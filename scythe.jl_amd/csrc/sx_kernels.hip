@@ -605,6 +605,7 @@ struct PhysArgsT {
     int64_t col0, col1;
     Planes<ST> G;
     const double *phi;
+    const double *ref;    // ReferenceState [3][3][nz] (Euler_test)
     int64_t NG;
     int L, nrings;
 };
@@ -629,6 +630,42 @@ __device__ __forceinline__ double ab_step(const A &a, int v, int64_t p, double u
 
 // value of variable v / derivative slot s (>= 1) of variable v at point p
 #define PSV(v) a.P.val[(int64_t)(v) * a.N + p]
+// Moist thermodynamics of Euler_test (src/thermodynamics.jl; constants :2-17, :31-32)
+namespace thermo {
+constexpr double Rd = 287.04, Rv = 461.50, Cvd = 716.96, Cvv = 1410.0, gravity = 9.81, L_v0 = 2.501e6, T_0 = 273.16, p_0 = 1000.0,
+                 q0 = 1.0e-7;
+constexpr double rho_d0 = 100.0 * p_0 / (T_0 * Rd);
+// rho_v0 = 100 sat_pressure_liquid(T_0) / (T_0 Rv), sat_pressure_liquid(T) = 6.112 exp(17.67 Tc / (Tc + 243.5)) (:19-23, :32)
+__device__ __forceinline__ double rho_v0() { const double Tc = T_0 - 273.15; return 100.0 * (6.112 * exp(17.67 * Tc / (Tc + 243.5))) / (T_0 * Rv); }
+__device__ __forceinline__ double ahyp(double mu) { return mu < 0.0 ? 0.0 : sqrt(mu * mu + q0 * q0) + mu - q0; }            // :190-198
+__device__ __forceinline__ double dmudq(double mu, double q_v) { return ((q_v + q0) - mu) / (q_v + q0); }                    // :200-203
+__device__ __forceinline__ double dry_density(double xi) { return rho_d0 * exp(xi); }                                        // :205-208
+__device__ __forceinline__ double temperature(double s, double rho_d, double q_v) {                                          // :67-80
+    const double Cf = Cvd + (q_v * Cvv);
+    double qf = 1.0;
+    if (q_v != 0.0) qf = pow(rho_d * q_v / rho_v0(), (q_v * Rv) / Cf);
+    const double rf = pow(rho_d / rho_d0, Rd / Cf);
+    const double Tf = exp((s - (q_v * L_v0 / T_0)) / Cf);
+    return T_0 * Tf * rf * qf;
+}
+__device__ __forceinline__ double P_s(double Tk, double rho_d, double q_v) {                                                 // :215-219
+    return Tk * ((rho_d * Rd) + (q_v * rho_d * Rv)) / (Cvd + (q_v * Cvv));
+}
+__device__ __forceinline__ double P_xi(double Tk, double rho_d, double q_v) {                                                // :221-224
+    return (Rd + (q_v * rho_d * Rv)) * ((rho_d * Tk) + P_s(Tk, rho_d, q_v));
+}
+__device__ __forceinline__ double P_qv(double Tk, double rho_d, double q_v) {                                                // :232-242
+    if (q_v == 0.0) return 0.0;
+    const double rho_v = q_v * rho_d;
+    double qf = Rv * (1 + log(rho_v / rho_v0())) - (Cvv * log(Tk / T_0)) - L_v0 / T_0;
+    qf *= P_s(Tk, rho_d, q_v);
+    return (rho_d * Rv * Tk) + qf;
+}
+__device__ __forceinline__ double pressure_gradient(double Tk, double rho_d, double q_v, double s_x, double xi_x, double qv_x) {   // :250-258
+    return (P_s(Tk, rho_d, q_v) * s_x) + (P_xi(Tk, rho_d, q_v) * xi_x) + (P_qv(Tk, rho_d, q_v) * qv_x);
+}
+}  // namespace thermo
+
 #define PS(v, s) ((double)a.P.der[((int64_t)((s) - 1) * a.V + (v)) * a.N + p])
 
 template <class ST>
@@ -708,8 +745,40 @@ __global__ void k_phys_pointwise(PhysArgsT<ST> a) {
             e[4] = e[4] + (-(pxi * xiz)) + d4;
             for (int v = 0; v < 5; v++) {
                 ab_step(a, v, p, PSV(v), e[v]);
-                a.In[(int64_t)v * a.N + p] = (v == 1) ? -wz : (v == 4) ? -(pxi * xiz) : 0.0;
+                if (a.In) a.In[(int64_t)v * a.N + p] = (v == 1) ? -wz : (v == 4) ? -(pxi * xiz) : 0.0;
             }
+        } break;
+        case SX_EQ_EULER_TEST: {               // src/testModels.jl:100-215
+            const double K = par[SX_P_K], pxi = par[SX_P_PXI_BAR];
+            const int k = (int)(p % a.nz), nz = a.nz;
+            // ReferenceState rows: sbar, sbar_z, sbar_zz, xibar, xibar_z, xibar_zz, mubar, mubar_z, mubar_zz
+            const double sbar = a.ref[k], sbar_z = a.ref[nz + k], xibar = a.ref[3 * nz + k], xibar_z = a.ref[4 * nz + k];
+            const double mubar = a.ref[6 * nz + k], mubar_z = a.ref[7 * nz + k];
+            const double s_x = PS(0, a.s_r), s_z = PS(0, a.s_z), xi_x = PS(1, a.s_r), xi_z = PS(1, a.s_z);
+            const double mu = PSV(2), mu_x = PS(2, a.s_r), mu_z = PS(2, a.s_z);
+            const double u = PSV(3), u_x = PS(3, a.s_r), u_z = PS(3, a.s_z), w = PSV(4), w_x = PS(4, a.s_r), w_z = PS(4, a.s_z);
+            const double q_v = thermo::ahyp(mu + mubar);
+            const double rho_d = thermo::dry_density(PSV(1) + xibar);
+            const double Tk = thermo::temperature(PSV(0) + sbar, rho_d, q_v);
+            const double rho_t = rho_d * (1.0 + q_v);
+            const double dm = thermo::dmudq(mu + mubar, q_v);
+            const double qvp_x = mu_x / dm, qvp_z = mu_z / dm;
+            const double rhobar = thermo::dry_density(xibar) * (1.0 + thermo::ahyp(mubar));
+            const double rho_p = rho_t - rhobar;
+            double e[5];
+            e[0] = ((-u * s_x) + (-w * (s_z + sbar_z))) + (K * (PS(0, a.s_rr) + PS(0, a.s_zz)));
+            e[1] = ((-u * xi_x) + (-w * (xi_z + xibar_z))) - u_x - w_z;
+            e[2] = ((-u * mu_x) + (-w * (mu_z + mubar_z))) + (K * (PS(2, a.s_rr) + PS(2, a.s_zz)));
+            e[3] = ((-u * u_x) + (-w * u_z)) + (-(thermo::pressure_gradient(Tk, rho_d, q_v, s_x, xi_x, qvp_x) / rho_t)) +
+                   (K * (PS(3, a.s_rr) + PS(3, a.s_zz)));
+            e[4] = ((-u * w_x) + (-w * w_z)) +
+                   (-(thermo::gravity * rho_p / rho_t) - (thermo::pressure_gradient(Tk, rho_d, q_v, s_z, xi_z, qvp_z) / rho_t)) +
+                   (K * (PS(4, a.s_rr) + PS(4, a.s_zz)));
+            for (int v = 0; v < 5; v++) {
+                ab_step(a, v, p, PSV(v), e[v]);
+                if (a.In) a.In[(int64_t)v * a.N + p] = (v == 1) ? -w_z : (v == 4) ? -(pxi * xi_z) : 0.0;      // impdot: only kept when semi-implicit
+            }
+            for (int v = 5; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
         } break;
         default: break;
     }
@@ -1183,7 +1252,7 @@ static PhysArgsT<ST> phys_args(sx_handle *h, int t) {
     a.In = h->d_I[0] ? h->d_I[h->rot % 3] : nullptr;
     a.np1 = h->d_np1;
     a.r = h->d_r; a.cosl = h->d_cosl; a.sinl = h->d_sinl; a.z = h->d_z;
-    a.MintT = h->d_MintT; a.MdzT = h->d_MdzT;
+    a.MintT = h->d_MintT; a.MdzT = h->d_MdzT; a.ref = h->d_ref;
     a.N = h->N; a.V = h->V; a.nz = h->nz; a.t = t; a.eq = h->eq;
     a.s_u = h->slot[0]; a.s_r = h->slot[1]; a.s_rr = h->slot[2]; a.s_l = h->slot[3]; a.s_ll = h->slot[4];
     a.s_z = h->slot[5]; a.s_zz = h->slot[6];

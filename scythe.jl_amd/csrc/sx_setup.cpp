@@ -271,7 +271,7 @@ bool build_cheb_ops(double zmin, double zmax, int nz, int Zb, int bcb, int bct, 
     xmat CA((size_t)N * Zb, 0.0L);
     for (int i = 0; i < N; i++)
         for (int k = 0; k < Zb; k++) CA[(size_t)i * Zb + k] = proj[(size_t)i * N + k];
-    xmat M0, M1, M2, TI, TICA, Mint, Mdz, Mrec;
+    xmat M0, M1, M2, TI, TICA, Mint, Mdz, Mrec, Mdzz;
     matmul(x.T, CA, M0, N, N, Zb);
     matmul(x.TD, CA, M1, N, N, Zb);
     matmul(x.TDD, CA, M2, N, N, Zb);
@@ -280,9 +280,10 @@ bool build_cheb_ops(double zmin, double zmax, int nz, int Zb, int bcb, int bct, 
     matmul(TICA, CB, Mint, N, Zb, N);
     matmul(M1, CB, Mdz, N, Zb, N);
     matmul(M0, CB, Mrec, N, Zb, N);
+    matmul(M2, CB, Mdzz, N, Zb, N);
     o.T = to_double(x.T); o.Dc = to_double(x.Dc); o.CB = to_double(CB); o.CA = to_double(CA);
     o.M[0] = to_double(M0); o.M[1] = to_double(M1); o.M[2] = to_double(M2);
-    o.Mint = to_double(Mint); o.Mdz = to_double(Mdz); o.Mrec = to_double(Mrec);
+    o.Mint = to_double(Mint); o.Mdz = to_double(Mdz); o.Mrec = to_double(Mrec); o.Mdzz = to_double(Mdzz);
     o.zmin = zmin; o.zmax = zmax;
     return true;
 }

@@ -124,6 +124,7 @@ class ModelParameters:
     grid_params: GridParameters = None
     physical_params: Dict = field(default_factory=dict)
     options: Dict = field(default_factory=lambda: {"semiimplicit": False, "exact_reference_state": False})
+    ref_state: object = None       # ReferenceState; built from ref_state_file when the equation set needs one and this is None
 
 
 # ----------------------------------------------------------------------------- descriptors
@@ -173,9 +174,18 @@ def model_desc(model: Optional[ModelParameters], patch: GridParameters):
             # getfield(Scythe, Symbol(...)) raises UndefVarError for an unknown name (src/semiimplicit.jl:359-361)
             raise ValueError("equation set %r is not defined on the HIP path" % model.equation_set)
         pp = {(k if isinstance(k, str) else str(k)).lstrip(":"): v for k, v in model.physical_params.items()}
+        opts = {str(k).lstrip(":"): v for k, v in (model.options or {}).items()}
+        if model.equation_set == "Euler_test":
+            # createModelTile builds mtile.ref_state from model.ref_state_file (src/semiimplicit.jl:44-124)
+            if model.ref_state is None:
+                from . import reference_state as RS
+                build = RS.exact_reference_state if opts.get("exact_reference_state", False) else RS.interpolate_reference_file
+                model.ref_state = build(model)
+            keep["ref"] = model.ref_state.packed()
+            m.ref_state = keep["ref"].ctypes.data_as(L.P_D)
+            pp.setdefault("Pxi_bar", model.ref_state.Pxi_bar)
         keep["par"] = (C.c_double * len(L.PARAM_ORDER))(*[float(pp.get(k, 0.0)) for k in L.PARAM_ORDER])
         m.ts, m.equation_set = model.ts, eq
-        opts = {str(k).lstrip(":"): v for k, v in (model.options or {}).items()}
         m.semiimplicit = int(bool(opts.get("semiimplicit", False)))
     m.params = keep["par"]
     m.w_index = patch.vars.get("w", 0)

@@ -53,6 +53,31 @@ def rz_semiimplicit(num_cells=8, zDim=12):
                 eq="LinearAcousticRZ", ts=2.0, par=dict(K=10.0, Pxi_bar=1.2e5), ic=ic, semiimplicit=True)
 
 
+def rz_euler(num_cells=8, zDim=12, semiimplicit=True):
+    """Euler_test (src/testModels.jl:100-215) about a stably stratified, slightly moist reference state.  The reference
+    profiles are analytic; their derivative columns come from the ORACLE's Chebyshev operators (the same filtered
+    CB -> CA -> CI / CIx / CIxx the reference applies, src/reference_state.jl:140-160) and are handed to both sides."""
+    zmax = 1.0e4
+    ch = O.Cheb(0.0, zmax, zDim, bdim=zDim)
+    z = ch.z
+    prof = dict(sbar=20.0 + 0.012 * z, xibar=-z / 8.5e3, mubar=0.5 * ((4e-3 * np.exp(-z / 2.5e3) + 1e-7) - 1e-14 / (4e-3 * np.exp(-z / 2.5e3) + 1e-7)))
+    ref = {}
+    for k, v in prof.items():
+        b = ch.CBm @ v
+        ref[k] = np.stack([ch.M[0] @ b, ch.M[1] @ b, ch.M[2] @ b], axis=1)
+
+    def ic(p):
+        r, zz = p[:, 0], p[:, 1]
+        b = np.exp(-((r - 1.0e4) / 4.0e3) ** 2 - ((zz - 4.0e3) / 2.0e3) ** 2)
+        s_ = np.sin(np.pi * zz / zmax)
+        return np.stack([0.5 * b, 1.0e-4 * b, 2.0e-4 * b, 0.5 * s_ * b, 0.2 * s_ * b], axis=1)
+    par = dict(K=10.0, Pxi_bar=1.0e5, ref_state=ref)
+    return dict(name="rz_euler", grid=dict(geometry="RZ", xmin=0.0, xmax=2.0e4, num_cells=num_cells, zmin=0.0, zmax=zmax,
+                                           zDim=zDim, b_zDim=zDim, vars={"s": 1, "xi": 2, "mu": 3, "u": 4, "w": 5},
+                                           BCB={"w": "R1T0"}, BCT={"w": "R1T0"}),
+                eq="Euler_test", ts=1.0, par=par, ic=ic, semiimplicit=semiimplicit)
+
+
 def rl_advection(num_cells=8, ring_L=None):
     def ic(p):
         r, l = p[:, 0], p[:, 1]
@@ -145,8 +170,12 @@ def hip_params(case, storage="f64"):
     g = dict(case["grid"])
     ring_L = g.pop("ring_L", None)
     gp = S.GridParameters(ring_uniform_L=ring_L or 0, storage=storage, **g)
-    mp = S.ModelParameters(ts=case["ts"], equation_set=case["eq"], grid_params=gp, physical_params=dict(case["par"]),
+    par = dict(case["par"])
+    rs = par.pop("ref_state", None)
+    mp = S.ModelParameters(ts=case["ts"], equation_set=case["eq"], grid_params=gp, physical_params=par,
                            options={"semiimplicit": case.get("semiimplicit", False)})
+    if rs is not None:
+        mp.ref_state = S.ReferenceState(rs["sbar"], rs["xibar"], rs["mubar"], np.zeros_like(rs["sbar"]), par["Pxi_bar"])
     return gp, mp
 
 

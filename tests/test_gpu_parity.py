@@ -202,3 +202,43 @@ def test_max_abs_diagnostic_matches_host_reduction():
     m.step()
     g = m.run.tiles[0]
     assert np.array_equal(g.max_abs(), np.abs(g.var_np1).max(axis=0))
+
+
+@pytest.mark.parametrize("semi", [True, False])
+def test_rz_euler_test_moist_equation_set(semi):
+    """Euler_test: moist thermodynamics in the pressure-gradient force, reference-state advection, AI2* adjustment.
+    Checked against the numpy oracle (the C port does not carry this equation set)."""
+    case = cases.rz_euler(semiimplicit=semi)
+    ref = cases.OracleModel(case, numpy_twin=True)
+    hip = cases.HipModel(case)
+    for _ in range(4):
+        ref.step()
+        hip.step()
+    assert cases.rel_err_per_var(hip.physical(), ref.physical()) < TOL
+
+
+def test_euler_test_with_reference_state_built_from_a_sounding_file(tmp_path):
+    """createModelTile's path: ModelParameters.ref_state_file -> interpolate_reference_file -> ReferenceState on the device
+    (Pxi_bar from the reference state), then the same run in the oracle fed with the same profiles."""
+    import scythe_jl_amd as S
+    case = cases.rz_euler(num_cells=6, zDim=16)
+    f = tmp_path / "sounding.txt"
+    f.write_text("1000.0 300.0 10.0\n" + "".join("%g %g %g\n" % (a, 300.0 + 4.0e-3 * a, 10.0 * np.exp(-a / 2.0e3))
+                                                 for a in np.linspace(250.0, 10500.0, 42)))
+    g = dict(case["grid"])
+    gp = S.GridParameters(**g)
+    mp = S.ModelParameters(ts=case["ts"], equation_set="Euler_test", grid_params=gp, physical_params={"K": 10.0},
+                           options={"semiimplicit": True}, ref_state_file=str(f))
+    run = S.ModelRun(mp)
+    rs = mp.ref_state
+    assert rs is not None and 300.0 ** 2 < rs.Pxi_bar < 360.0 ** 2
+    pts = S.getGridpoints(run.tiles[0])
+    run.set_initial_conditions([case["ic"](pts.reshape(len(pts), -1))])
+    case["par"] = dict(K=10.0, Pxi_bar=rs.Pxi_bar, ref_state=dict(sbar=rs.sbar, xibar=rs.xibar, mubar=rs.mubar))
+    ref = cases.OracleModel(case, numpy_twin=True)
+    for _ in range(3):
+        run.step()
+        ref.step()
+    assert not run.tiles[0].check_nan()
+    assert cases.rel_err_per_var(run.physical(), ref.physical()) < TOL
+    run.close()

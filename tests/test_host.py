@@ -1,4 +1,5 @@
 """CPU-only: the host-side mirror of the reference interface (no compute)."""
+import pytest
 import numpy as np
 
 import scythe_jl_amd as S
@@ -70,3 +71,78 @@ def test_csv_reader_matches_notebook_format(tmp_path):
     vals = read_physical_grid(str(path), gp, FakeRun)
     assert [v.shape for v in vals] == [(4, 2), (2, 2)]
     assert np.array_equal(vals[0][:, 0], data[:4, 3]) and np.array_equal(vals[1][:, 1], data[4:, 2])
+
+
+# ----------------------------------------------------------------------------- Chebyshev column ops / reference state
+def test_chebyshev_column_ops_match_the_oracle_operators():
+    """sx_cheb_column_ops (the library's extended-precision assembly) against the oracle's Cheb class: filtered values,
+    first / second derivative and integral from the bottom, with truncation and with vertical BCs."""
+    from oracle import oracle_np as O
+    for n, bd, bcb, bct in [(12, 12, "R0", "R0"), (20, 0, "R0", "R0"), (16, 11, "R1T0", "R1T1"), (33, 0, "R1T1", "R0")]:
+        col = S.Chebyshev1D(0.0, 2.5e3, n, bd, bcb, bct)
+        ch = O.Cheb(0.0, 2.5e3, n, bdim=bd or None, bcb=bcb, bct=bct)
+        assert np.allclose(col.z, ch.z, rtol=0, atol=1e-9)
+        scale = lambda m: np.abs(m).max()
+        for mine, ref in [(col._rec, ch.M[0] @ ch.CBm), (col._dz, ch.M[1] @ ch.CBm), (col._dzz, ch.M[2] @ ch.CBm),
+                          (col._int, ch.T @ ch.Ic @ ch.CAm @ ch.CBm)]:
+            assert np.abs(mine - ref).max() <= 1e-12 * scale(ref)
+
+
+def _dry_isentropic(gp, theta0=300.0, psfc=1000.0):
+    alt = np.linspace(0.0, gp.zmax, 41)
+    return S.reference_state.reference_state_from_sounding(gp, psfc, alt, np.full(41, theta0), np.zeros(41))
+
+
+def test_reference_state_of_a_dry_isentropic_atmosphere():
+    """theta = 300 K, no vapour: Exner pressure is linear in z, so p(z), T(z) are known in closed form.
+    interpolate_reference_file integrates ln p level by level with the density of the level below and then re-integrates
+    once with the Chebyshev column (src/reference_state.jl:70-111) - a first-order scheme with one correction - so the
+    result approaches the closed form as the column is refined, while these hold to rounding at any resolution: the
+    potential temperature recovered from (sbar, xibar) is 300 K, the surface pressure is the sounding's, mubar =
+    bhyp(0) = 0, the derivative columns are the column operators applied to the values, Pxi_bar = mean(gamma Rd T)."""
+    T = S.thermodynamics
+    err = []
+    for nz in (24, 48):
+        gp = S.GridParameters(geometry="RZ", xmin=0.0, xmax=1.0e4, num_cells=6, zmin=0.0, zmax=1.0e4, zDim=nz, b_zDim=nz,
+                              vars={"s": 1, "xi": 2, "mu": 3, "u": 4, "w": 5})
+        rs = _dry_isentropic(gp)
+        col = S.Chebyshev1D(0.0, 1.0e4, nz, nz)
+        exner = 1.0 - T.gravity * col.z / (T.Cpd * 300.0)
+        q_v, rho_d, Tk, p = T.thermodynamic_tuple(rs.sbar[:, 0], rs.xibar[:, 0], rs.mubar[:, 0])
+        assert np.abs(Tk * (T.p_0 / p) ** (T.Rd / T.Cpd) - 300.0).max() < 1e-9
+        assert abs(p[0] - 1000.0) < 1e-9
+        assert np.abs(rs.mubar).max() < 1e-20 and np.abs(q_v).max() < 1e-12      # bhyp(0) = 0 up to rounding of q0 - q0^2 / q0
+        col.uMish[:] = rs.xibar[:, 0]
+        assert np.abs(col.CIxtransform() - rs.xibar[:, 1]).max() < 1e-12 * np.abs(rs.xibar[:, 1]).max()
+        assert np.abs(col.CIxxtransform() - rs.xibar[:, 2]).max() < 1e-9 * np.abs(rs.xibar[:, 2]).max()
+        assert abs(rs.Pxi_bar / ((T.Cpd / T.Cvd) * T.Rd * Tk).mean() - 1.0) < 1e-12
+        assert rs.packed().shape == (3, 3, nz)
+        err.append(np.abs(p / (1000.0 * exner ** (T.Cpd / T.Rd)) - 1.0).max())
+    assert err[0] < 0.02 and err[1] < 0.6 * err[0]          # 1.2 % at 24 levels, shrinking with resolution
+
+
+def test_reference_state_file_readers(tmp_path):
+    """interpolate_reference_file parses `psfc theta qv` + `alt theta qv` lines and refuses levels above the sounding
+    (src/reference_state.jl:17-68); exact_reference_state checks the level heights (src/reference_state.jl:170-180)."""
+    gp = S.GridParameters(geometry="RZ", xmin=0.0, xmax=1.0e4, num_cells=6, zmin=0.0, zmax=8.0e3, zDim=10, b_zDim=10,
+                          vars={"s": 1, "xi": 2, "mu": 3, "u": 4, "w": 5})
+    f = tmp_path / "sounding.txt"
+    f.write_text("1000.0 300.0 14.0\n" + "".join("%g %g %g\n" % (a, 300.0 + 3.0e-3 * a, 14.0 * np.exp(-a / 2.5e3))
+                                                 for a in np.linspace(500.0, 9000.0, 18)))
+    mp = S.ModelParameters(equation_set="Euler_test", grid_params=gp, ref_state_file=str(f))
+    rs = S.reference_state.interpolate_reference_file(mp)
+    assert rs.sbar.shape == (10, 3) and np.all(np.isfinite(rs.sbar)) and rs.mubar[0, 0] > rs.mubar[-1, 0] > 0.0
+    assert 300.0 ** 2 < rs.Pxi_bar < 360.0 ** 2
+    f.write_text("1000.0 300.0 14.0\n500.0 301.0 12.0\n")            # sounding ends below the model top
+    with pytest.raises(ValueError):
+        S.reference_state.interpolate_reference_file(mp)
+    z = S.Chebyshev1D(0.0, 8.0e3, 10, 10).z
+    g = tmp_path / "exact.txt"
+    g.write_text("".join("%r %r %r %r 0.0\n" % (float(zz), float(a), float(b), float(c))
+                         for zz, a, b, c in zip(z, rs.sbar[:, 0], rs.xibar[:, 0], rs.mubar[:, 0])))
+    mp2 = S.ModelParameters(equation_set="Euler_test", grid_params=gp, ref_state_file=str(g), options={"exact_reference_state": True})
+    ex = S.reference_state.exact_reference_state(mp2)
+    assert np.abs(ex.sbar[:, 0] - rs.sbar[:, 0]).max() < 1e-9 * np.abs(rs.sbar[:, 0]).max()
+    g.write_text("".join("%r 1.0 1.0 1.0 0.0\n" % float(zz + 1.0) for zz in z))
+    with pytest.raises(ValueError):
+        S.reference_state.exact_reference_state(mp2)
