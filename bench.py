@@ -160,7 +160,9 @@ def main():
     for _ in range(args.warmup):
         run.step()
     barrier()
-    tile.enable_timers(True)
+    # per-kernel hipEvent timers feed the roofline object, which only rank 0 prints: the other ranks skip the two event
+    # records per launch (at N = 8 a step is ~10 launches of ~30 us each, so the records are not free)
+    tile.enable_timers(rank == 0)
     tile.reset_timers()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -422,13 +422,18 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     // ---- Chebyshev operators
     if (h->has_z) {
         const int nz = h->nz, Zb = h->Zb;
-        std::vector<double> Mz((size_t)h->V * 3 * nz * Zb);
+        std::vector<double> Mz((size_t)h->V * 3 * nz * Zb), MzT(Mz.size());
         std::vector<ChebOps> ops(h->V);
         for (int v = 0; v < h->V; v++) {
             if (!build_cheb_ops(h->zmin, h->zmax, nz, Zb, h->bcb[v], h->bct[v], ops[v], err)) { set_error(err); FAIL(); }
-            for (int d = 0; d < 3; d++)
-                std::copy(ops[v].M[d].begin(), ops[v].M[d].end(), Mz.begin() + ((size_t)v * 3 + d) * nz * Zb);
+            for (int d = 0; d < 3; d++) {
+                const size_t o = ((size_t)v * 3 + d) * nz * Zb;
+                std::copy(ops[v].M[d].begin(), ops[v].M[d].end(), Mz.begin() + o);
+                for (int i = 0; i < nz; i++)                     // [Zb][nz] copy for the matrix-core kernel (k_colmat_mfma)
+                    for (int k = 0; k < Zb; k++) MzT[o + (size_t)k * nz + i] = ops[v].M[d][(size_t)i * Zb + k];
+            }
         }
+        if (!upload(h, &h->d_MzT, MzT)) FAIL();
         const ChebOps &cop = ops[h->col_var - 1 < h->V ? h->col_var - 1 : 0];
         std::vector<double> zv = cop.z;
         if (!upload(h, &h->d_Mz, Mz) || !upload(h, &h->d_CB, ops[0].CB) || !upload(h, &h->d_z, zv)) FAIL();

@@ -120,6 +120,7 @@ struct sx_handle {
     int *d_L = nullptr, *d_kmax = nullptr;
     int64_t *d_pstart = nullptr, *d_twoff = nullptr, *d_phoff = nullptr;
     double2 *d_tw = nullptr, *d_ph = nullptr;
+    double *d_MzT = nullptr;    // operators of d_Mz transposed: [v][sz][Zb][nz]
     double *d_Mz = nullptr, *d_CB = nullptr, *d_MintT = nullptr, *d_MdzT = nullptr, *d_MrecT = nullptr;
     double *d_WT[2] = {}, *d_XT[2] = {};
     double tau[2] = {0, 0};

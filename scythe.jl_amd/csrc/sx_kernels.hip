@@ -67,6 +67,47 @@ k_colmat(const double *__restrict__ in, double *__restrict__ out, const double *
     }
 }
 
+// The same product on the f64 matrix cores for n_out a multiple of 16 (zDim 32 / 64 / 128): wave = (16 wavenumber blocks) x
+// all n_out outputs, K = n_in in steps of 4.  B comes straight from the A-coefficient rows (16 consecutive blocks = one
+// 128-byte line per k), the operator fragments are shared by every wave of the launch (L1 / L2 resident), the result
+// tile is stored as 128-byte lines: no LDS, no barrier, and the scalar operator loads of k_colmat (its limiter) are gone.
+typedef double colmat_d4 __attribute__((ext_vector_type(4)));
+
+template <int MT>          // n_out / 16
+__global__ void __launch_bounds__(256)
+k_colmat_mfma(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ mats,
+              const ColJob *__restrict__ jobs, int n_in, int K2, int64_t in_row, int64_t out_row, int row0) {
+    constexpr int n_out = MT * 16;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = lane & 15, kk = lane >> 4;
+    const int blk0 = (blockIdx.x * 4 + wave) * 16;
+    if (blk0 >= K2) return;
+    const int blk = min(blk0 + n, K2 - 1);
+    const ColJob job = jobs[blockIdx.y];
+    const double *src = in + (int64_t)(row0 + blockIdx.z) * in_row + job.in_off + blk;
+    double *dst = out + (int64_t)blockIdx.z * out_row + job.out_off;
+    const double *MTr = mats + job.mat_off;                // operator transposed: [n_in][n_out]
+    colmat_d4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[t] = colmat_d4{0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < n_in; k0 += 4) {
+        const int k = k0 + kk;
+        const bool kin = k < n_in;
+        const double b = kin ? src[(int64_t)k * K2] : 0.0;                      // B[k][n]: coefficient row k, block n
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+            const double a = kin ? MTr[(int64_t)k * n_out + t * 16 + n] : 0.0;   // A[m = lane & 15][k], 128-byte rows
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    if (blk0 + n < K2) {
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(int64_t)(t * 16 + kk + 4 * r) * K2 + blk0 + n] = acc[t][r];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ radial + azimuthal inverse
 // One workgroup per (z-chunk, variable, ring): radial evaluation (4 rows of Az), phase reference, truncated inverse
 // DFT with lambda-derivatives, stores straight into the reference physical layout (z innermost => 128-B lines).
@@ -1206,9 +1247,14 @@ void launch_zinv(sx_handle *h, bool full) {
     h->last_zinv_jobs = njobs;
     if (njobs > 0) {
         dim3 g((h->K2 + 63) / 64, njobs, h->nbt);
-        hipLaunchKernelGGL(k_colmat, g, dim3(64, 4), sizeof(double) * 64 * h->Zb, h->stream, h->d_A, h->d_Az, h->d_Mz,
-                           full ? h->d_jobs_zinv_full : h->d_jobs_zinv_eq, h->Zb, h->nz, h->K2, h->C,
-                           (int64_t)h->V * 3 * h->nz * h->K2, h->cell0);
+        const ColJob *jobs = full ? h->d_jobs_zinv_full : h->d_jobs_zinv_eq;
+        const int64_t azrow = (int64_t)h->V * 3 * h->nz * h->K2;
+        if (h->nz == 64) hipLaunchKernelGGL(k_colmat_mfma<4>, g, dim3(256), 0, h->stream, h->d_A, h->d_Az, h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0);
+        else if (h->nz == 32) hipLaunchKernelGGL(k_colmat_mfma<2>, g, dim3(256), 0, h->stream, h->d_A, h->d_Az, h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0);
+        else if (h->nz == 128) hipLaunchKernelGGL(k_colmat_mfma<8>, g, dim3(256), 0, h->stream, h->d_A, h->d_Az, h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0);
+        else
+            hipLaunchKernelGGL(k_colmat, g, dim3(64, 4), sizeof(double) * 64 * h->Zb, h->stream, h->d_A, h->d_Az, h->d_Mz, jobs,
+                               h->Zb, h->nz, h->K2, h->C, azrow, h->cell0);
         HIPCHK(hipGetLastError());
     }
     timer_end(h);
