@@ -458,52 +458,52 @@ __device__ __forceinline__ void solve_columns(const double *__restrict__ Bsrc, c
         T bl0 = zero(tp), bl1 = zero(tp), br0 = zero(tp), br1 = zero(tp);
         for (int q = 0; q < rl; q++) { const T bq = BROW(q); bl0 = bl0 + g_l[q * 2] * bq; bl1 = bl1 + g_l[q * 2 + 1] * bq; }
         for (int q = 0; q < rr; q++) { const T bq = BROW(nb - 1 - q); br0 = br0 + g_r[q * 2] * bq; br1 = br1 + g_r[q * 2 + 1] * bq; }
-        for (int i0 = 0; i0 < n; i0 += SOLVE_U) {
+        // Full batches of SOLVE_U rows run without any control flow (row index tests are selects), so the compiler hoists the
+        // wave-uniform factor loads of a whole batch in front of its dependent multiply-adds; with a branch per row every row
+        // waited for its own scalar loads (~700 cycles per row, the whole kernel).  The remainder rows take the simple loop.
+        auto fwd_row = [&](int i, T s) {
+            s = s + (i == 0 ? 1.0 : 0.0) * bl0 + (i == 1 ? 1.0 : 0.0) * bl1;
+            s = s + (i == n - 1 ? 1.0 : 0.0) * br0 + (i == n - 2 ? 1.0 : 0.0) * br1;
+            const double *l = Lb + (int64_t)i * 4;
+            s = s - (l[2] * y1 + l[1] * y2 + l[0] * y3);
+            s = Ld[i] * s;
+            y3 = y2; y2 = y1; y1 = s;
+            ASET(rl + i, s);
+        };
+        const int nfull = (n / SOLVE_U) * SOLVE_U;
+        for (int i0 = 0; i0 < nfull; i0 += SOLVE_U) {
             T rhs[SOLVE_U];
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) rhs[u] = (i0 + u < n) ? BROW(rl + i0 + u) : zero(tp);
+            for (int u = 0; u < SOLVE_U; u++) rhs[u] = BROW(rl + i0 + u);
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) {
-                const int i = i0 + u;
-                if (i < n) {
-                    T s = rhs[u];
-                    if (i == 0) s = s + bl0;
-                    if (i == 1) s = s + bl1;
-                    if (i == n - 1) s = s + br0;
-                    if (i == n - 2) s = s + br1;
-                    const double *l = Lb + (int64_t)i * 4;
-                    s = s - (l[2] * y1 + l[1] * y2 + l[0] * y3);
-                    s = Ld[i] * s;
-                    y3 = y2; y2 = y1; y1 = s;
-                    ASET(rl + i, s);
-                }
-            }
+            for (int u = 0; u < SOLVE_U; u++) fwd_row(i0 + u, rhs[u]);
         }
+        for (int i = nfull; i < n; i++) fwd_row(i, BROW(rl + i));
         // back substitution
         T x1 = zero(tp), x2 = zero(tp), x3 = zero(tp);     // x[i+1], x[i+2], x[i+3]
         T xl0 = zero(tp), xl1 = zero(tp), xr0 = zero(tp), xr1 = zero(tp);
-        for (int i0 = n - 1; i0 >= 0; i0 -= SOLVE_U) {
+        // factor rows i + 1 .. i + 3 are read unconditionally (clamped to the last row) and masked by a select
+        auto bwd_row = [&](int i, T s) {
+            const int i1 = min(i + 1, n - 1), i2 = min(i + 2, n - 1), i3 = min(i + 3, n - 1);
+            s = s - ((i + 1 < n ? Lb[(int64_t)i1 * 4 + 2] : 0.0) * x1 + (i + 2 < n ? Lb[(int64_t)i2 * 4 + 1] : 0.0) * x2 +
+                     (i + 3 < n ? Lb[(int64_t)i3 * 4 + 0] : 0.0) * x3);
+            s = Ld[i] * s;
+            x3 = x2; x2 = x1; x1 = s;
+            AFIN(rl + i, s);
+            xr0 = (i == n - 1) ? s : xr0;
+            xr1 = (i == n - 2) ? s : xr1;
+            xl1 = (i == 1) ? s : xl1;
+            xl0 = (i == 0) ? s : xl0;
+        };
+        int ib = n - 1;
+        for (; ib >= SOLVE_U - 1; ib -= SOLVE_U) {
             T rhs[SOLVE_U];
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) rhs[u] = (i0 - u >= 0) ? AROW(rl + i0 - u) : zero(tp);
+            for (int u = 0; u < SOLVE_U; u++) rhs[u] = AROW(rl + ib - u);
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) {
-                const int i = i0 - u;
-                if (i >= 0) {
-                    T s = rhs[u];
-                    if (i + 1 < n) s = s - Lb[(int64_t)(i + 1) * 4 + 2] * x1;
-                    if (i + 2 < n) s = s - Lb[(int64_t)(i + 2) * 4 + 1] * x2;
-                    if (i + 3 < n) s = s - Lb[(int64_t)(i + 3) * 4 + 0] * x3;
-                    s = Ld[i] * s;
-                    x3 = x2; x2 = x1; x1 = s;
-                    AFIN(rl + i, s);
-                    if (i == n - 1) xr0 = s;
-                    if (i == n - 2) xr1 = s;
-                    if (i == 1) xl1 = s;
-                    if (i == 0) xl0 = s;
-                }
-            }
+            for (int u = 0; u < SOLVE_U; u++) bwd_row(ib - u, rhs[u]);
         }
+        for (; ib >= 0; ib--) bwd_row(ib, AROW(rl + ib));
         for (int q = 0; q < rl; q++) AFIN(q, g_l[q * 2] * xl0 + g_l[q * 2 + 1] * xl1);
         for (int q = 0; q < rr; q++) AFIN(nb - 1 - q, g_r[q * 2] * xr0 + g_r[q * 2 + 1] * xr1);
     } else {
