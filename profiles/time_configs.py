@@ -47,7 +47,7 @@ if __name__ == "__main__":
             config4_native_equivalent(), steps=10, warmup=3)
         sys.exit(0)
     c2 = cases.config2_literal()
-    run("config 2: RL cha_bell2024 Oneway slab, 100 cells, native ragged rings (direct DFT)", c2)
+    run("config 2: RL cha_bell2024 Oneway slab, 100 cells, native ragged rings (matrix-core DFT)", c2)
     c2u = cases.config2_literal()
     c2u["grid"]["ring_L"] = 256
     run("config 2 on uniform 256-point rings (FFT path)", c2u)

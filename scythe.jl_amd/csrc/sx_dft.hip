@@ -153,20 +153,129 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ inverse, RL grids
+// Without a vertical dimension the MFMA columns are the requested (variable, derivative plane) pairs of the ring (19 for the
+// shallow-water slab sets): all coefficient sets - value, d/dr, d2/dr2 by radial evaluation, d/dlambda, d2/dlambda2 by
+// i k / -k^2 - are formed once while staging, so one generated twiddle tile serves every plane.
+struct PlaneCols {
+    int n;                    // columns in use (<= 16: one MFMA column tile per pass)
+    int v[16], slot[16];      // column -> variable, derivative slot
+    int colof[8][5];          // variable, kind (u, r, rr, l, ll) -> column or -1
+};
+struct PlaneGroups { int ng; PlaneCols g[3]; };    // 16 columns per group; blockIdx.z picks the group
+constexpr int CSTP = 17;      // row stride of the 16-column coefficient tile
+
+template <class ST>
+__global__ void __launch_bounds__(512)
+k_rl_inverse_dft_planes(const double *__restrict__ A, Planes<ST> phys, const double *__restrict__ phi, const int *__restrict__ Lr,
+                        const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
+                        const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
+                        int K2, int nrings, int64_t N, int64_t arow, PlaneGroups pgs, int ring0, int lcap) {
+    extern __shared__ double sm[];
+    const PlaneCols &pc = pgs.g[blockIdx.z];
+    // one ring has too little work per plane to fill the chip with a workgroup per ring (300 rings at config 2): the ring's
+    // row tiles are split over gridDim.y workgroups, each staging the (small) coefficient tile for itself
+    const int ring = ring0 + blockIdx.x;
+    const int part = blockIdx.y, nparts = gridDim.y;
+    const int L = Lr[ring], km = kmaxr[ring];
+    if (part * (int)(blockDim.x >> 6) * 16 >= L) return;        // nothing for this part (uniform for the workgroup)
+    const int J4 = (2 * km + 1 + 3) & ~3;
+    double2 *twl = reinterpret_cast<double2 *>(sm);
+    double *C = sm + 2 * (size_t)lcap;                          // [J4][CSTP]
+    const int j0 = ring / MUBAR;
+    const double2 *phr = ph + phoff[ring];
+    const int64_t p0 = pstart[ring];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
+    for (int e = tid; e < J4 * CSTP; e += blockDim.x) C[e] = 0.0;
+    __syncthreads();
+    const double *pf = phi + (int64_t)ring * 4;
+    for (int e = tid; e < V * (km + 1); e += blockDim.x) {
+        const int k = e % (km + 1), v = e / (km + 1);
+        const double *a = A + (int64_t)j0 * arow + (int64_t)v * K2 + 2 * k;
+        double cr[3], ci[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double *f = pf + (int64_t)d * nrings * 4;
+            cr[d] = f[0] * a[0] + f[1] * a[arow] + f[2] * a[2 * arow] + f[3] * a[3 * arow];
+            ci[d] = (k == 0) ? 0.0 : f[0] * a[1] + f[1] * a[arow + 1] + f[2] * a[2 * arow + 1] + f[3] * a[3 * arow + 1];
+            if (k > 0) {
+                const double2 w = phr[k];
+                const double tr = cr[d] * w.x - ci[d] * w.y;
+                ci[d] = 2.0 * (cr[d] * w.y + ci[d] * w.x);
+                cr[d] = 2.0 * tr;
+            }
+        }
+        const int rr_ = (k == 0) ? 0 : 2 * k - 1, ri_ = 2 * k;      // rows of the cos / -sin coefficient
+#pragma unroll
+        for (int kind = 0; kind < 5; kind++) {
+            const int c = pc.colof[v][kind];
+            if (c < 0) continue;
+            double xr, xi;
+            if (kind < 3) { xr = cr[kind]; xi = ci[kind]; }
+            else if (kind == 3) { xr = -(double)k * ci[0]; xi = (double)k * cr[0]; }
+            else { xr = -((double)k * k) * cr[0]; xi = -((double)k * k) * ci[0]; }
+            C[rr_ * CSTP + c] = xr;
+            if (k > 0) C[ri_ * CSTP + c] = xi;
+        }
+    }
+    __syncthreads();
+    const int i = lane & 15, kk = lane >> 4;
+    const bool is_cos = kk & 1;
+    for (int mt = part * nw + wave; mt * 16 < L; mt += 2 * nw * nparts) {
+        const int mtb = mt + nw * nparts;
+        const bool two = mtb * 16 < L;
+        const int l0 = min(mt * 16 + i, L - 1), l1 = min(mtb * 16 + i, L - 1);
+        int k = (kk + 1) >> 1;
+        int m0 = (int)(((int64_t)k * l0) % L), m1 = (int)(((int64_t)k * l1) % L);
+        int s0 = 2 * l0, s1 = 2 * l1;
+        if (s0 >= L) s0 -= L;
+        if (s1 >= L) s1 -= L;
+        dft_d4 a00 = {0.0, 0.0, 0.0, 0.0}, a10 = a00;                            // the two row tiles
+        for (int js = 0; js < J4 / 4; js++) {
+            const double2 t0 = twl[m0], t1 = twl[m1];
+            double a0 = is_cos ? t0.x : -t0.y, a1 = is_cos ? t1.x : -t1.y;
+            if (js == 0 && kk == 0) { a0 = 1.0; a1 = 1.0; }
+            const double b0 = C[(4 * js + kk) * CSTP + i];
+            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, a00, 0, 0, 0);
+            if (two) a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, a10, 0, 0, 0);
+            m0 += s0;
+            if (m0 >= L) m0 -= L;
+            m1 += s1;
+            if (m1 >= L) m1 -= L;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if ((half && !two) || i >= pc.n) continue;
+            const dft_d4 &acc = half ? a10 : a00;
+            const int vv = pc.v[i], sl = pc.slot[i];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int lo = (half ? mtb : mt) * 16 + kk + 4 * r;
+                if (lo >= L) continue;
+                if (sl == 0) phys.val[(int64_t)vv * N + p0 + lo] = acc[r];
+                else phys.der[((int64_t)(sl - 1) * V + vv) * N + p0 + lo] = (ST)acc[r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // Workgroup = (16 levels, variable, ring).  The ring's points are staged LCH at a time as X[l][level]; wave w owns the
 // wavenumber tiles nt = w, w + nw, ... (16 columns j each, at most NTW per wave) and keeps their accumulators across chunks.
 constexpr int LCH = 256;      // ring points per staged chunk
-constexpr int NTW = 4;        // column tiles per wave: 8 waves x 4 x 16 = 512 columns >= 2 kmax + 2 for kmax <= 255
+constexpr int NTW = 5;        // column tiles per wave: 8 waves x 5 x 16 = 640 columns >= 2 kmax + 2 for kmax <= 319
 
 __global__ void __launch_bounds__(512)
 k_fl_forward_dft(const double *__restrict__ np1, double *__restrict__ Fl, const int *__restrict__ Lr,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
                  const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V, int nz,
-                 int K2, int64_t N, int ring0, int lcap) {
+                 int K2, int64_t N, int ring0, int lcap, int planes, int ntw) {
+    // planes = 0: the 16 MFMA rows are vertical levels of variable blockIdx.y (RLZ / RZ: z innermost in var_np1).
+    // planes = 1: grids without a vertical dimension - the rows are the V variables of the ring (var_np1 is [v][point]).
     extern __shared__ double sm[];
-    const int ring = ring0 + blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * DZC;
-    const int zc = min(DZC, nz - z0);
+    const int ring = ring0 + blockIdx.z, v = planes ? 0 : blockIdx.y, z0 = planes ? 0 : blockIdx.x * DZC;
+    const int zc = planes ? V : min(DZC, nz - z0);
     const int L = Lr[ring], km = kmaxr[ring];
     const int J = 2 * km + 2;                                   // columns: blk 0 (k = 0), blk 1 (padding), Re / Im of k >= 1
     double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]
@@ -176,23 +285,28 @@ k_fl_forward_dft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
     const int n = lane & 15, kk = lane >> 4;
+    // planes mode: the ring's column tiles are split over gridDim.y workgroups (a workgroup per ring would leave most of
+    // the chip idle on RL grids); tile of (wave, q) = (part * ntw + q) * nw + wave, part = 0 otherwise
+    const int tile0 = planes ? (int)blockIdx.y * ntw * nw : 0;      // ntw <= NTW column tiles per wave
+    if (tile0 * 16 >= J) return;
     dft_d4 acc[NTW];
 #pragma unroll
     for (int q = 0; q < NTW; q++) acc[q] = dft_d4{0.0, 0.0, 0.0, 0.0};
-    const double *x = np1 + (int64_t)v * N + p0 * nz + z0;
+    const double *x = planes ? np1 + p0 : np1 + (int64_t)v * N + p0 * nz + z0;
+    const int64_t sl = planes ? 1 : nz, szz = planes ? N : 1;        // strides of a ring point / of a row in var_np1
 
     for (int lc = 0; lc < L; lc += LCH) {
         const int ln = min(LCH, L - lc);                        // multiple of 4 (L is)
         __syncthreads();
         for (int o = tid; o < ln * DZC; o += blockDim.x) {
             const int zz = o & (DZC - 1), l = o >> 4;
-            X[l * CST + zz] = (zz < zc) ? x[(int64_t)(lc + l) * nz + zz] : 0.0;
+            X[l * CST + zz] = (zz < zc) ? x[(int64_t)(lc + l) * sl + zz * szz] : 0.0;
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NTW; q++) {
-            const int nt = wave + q * nw;
-            if (nt * 16 >= J) continue;
+            const int nt = tile0 + wave + q * nw;
+            if (q >= ntw || nt * 16 >= J) continue;
             // this lane's B column: j = nt * 16 + n -> wavenumber k = j / 2 (cos for even j, -sin for odd j)
             const int j = nt * 16 + n;
             const int k = min(j >> 1, km);
@@ -215,8 +329,8 @@ k_fl_forward_dft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     const double inv = 1.0 / L;
 #pragma unroll
     for (int q = 0; q < NTW; q++) {
-        const int nt = wave + q * nw;
-        if (nt * 16 >= J) continue;
+        const int nt = tile0 + wave + q * nw;
+        if (q >= ntw || nt * 16 >= J) continue;
         const int j = nt * 16 + n;
         const int k = j >> 1;
         const double2 w = phr[min(k, km)];
@@ -230,14 +344,19 @@ k_fl_forward_dft(const double *__restrict__ np1, double *__restrict__ Fl, const 
             else if (j == 1) out = 0.0;
             else if (!(j & 1)) out = (mine * w.x + other * w.y) * inv;      // Re: sr w.x + si w.y
             else out = (mine * w.x - other * w.y) * inv;                    // Im: si w.x - sr w.y
-            if (j < J && zz < zc) Fl[(((int64_t)ring * V + v) * nz + z0 + zz) * K2 + j] = out;
+            // Fl [ring][v][z][blk]: row zz is level z0 + zz of variable v, or (planes) variable zz of a grid with nz = 1
+            if (j < J && zz < zc) Fl[(planes ? (int64_t)ring * V + zz : ((int64_t)ring * V + v) * nz + z0 + zz) * K2 + j] = out;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
+// grids without a vertical dimension: columns = (variable, plane)
+static bool dft_planes(const sx_handle *h) { return !h->has_z; }
+
 bool dft_mfma_ok(const sx_handle *h) {
-    if (!h->has_l || fft_path_ok(h) || h->nz < 8 || h->kmax_max > 255) return false;
+    if (!h->has_l || fft_path_ok(h) || h->kmax_max > 319) return false;
+    if (dft_planes(h) ? (h->V > 8 || h->D > 5) : h->nz < 8) return false;
     static const bool off = getenv("SX_DFT_MFMA") && atoi(getenv("SX_DFT_MFMA")) == 0;       // scalar kernels instead (debugging)
     if (off) return false;
     return h->L_all_mult4;
@@ -246,8 +365,8 @@ bool dft_mfma_ok(const sx_handle *h) {
 // Rings are launched in classes of growing size so that the small ones do not pay the LDS footprint (and with it the
 // occupancy) of the largest: class c covers rings [c n/4, (c+1) n/4), sized for its last ring.
 template <class F>
-static void for_ring_classes(sx_handle *h, int n_rings, F f) {
-    const int ncls = n_rings >= 16 ? 4 : 1;
+static void for_ring_classes(sx_handle *h, int n_rings, F f, int max_classes = 4) {
+    const int ncls = n_rings >= 16 ? max_classes : 1;
     for (int c = 0; c < ncls; c++) {
         const int r0 = (int)((int64_t)n_rings * c / ncls), r1 = (int)((int64_t)n_rings * (c + 1) / ncls);
         if (r1 <= r0) continue;
@@ -257,9 +376,54 @@ static void for_ring_classes(sx_handle *h, int n_rings, F f) {
     }
 }
 
+static void launch_rl_inverse_dft_planes(sx_handle *h, bool full) {
+    const std::vector<int> &mask = full ? h->hmask_full : h->hmask_eq;
+    // kinds in slot order for RL grids: u, r, rr, l, ll  (slot[0..4])
+    PlaneGroups pgs;
+    pgs.ng = 0;
+    PlaneCols pc;
+    auto reset = [&]() { pc.n = 0; for (auto &row : pc.colof) for (int &c : row) c = -1; };
+    auto push = [&]() { if (pgs.ng < 3) pgs.g[pgs.ng++] = pc; reset(); };
+    reset();
+    for (int v = 0; v < h->V; v++) {
+        int need = 0;
+        for (int kind = 0; kind < 5; kind++) need += (h->slot[kind] >= 0 && ((mask[v] >> h->slot[kind]) & 1));
+        if (pc.n + need > 16) push();
+        for (int kind = 0; kind < 5; kind++) {
+            const int sl = h->slot[kind];
+            if (sl < 0 || !((mask[v] >> sl) & 1)) continue;
+            pc.colof[v][kind] = pc.n; pc.v[pc.n] = v; pc.slot[pc.n] = sl; pc.n++;
+        }
+    }
+    if (pc.n > 0) push();                       // V <= 8 variables x 5 planes = 40 columns at most: 3 groups
+    if (pgs.ng == 0) return;
+    const double *a = h->d_A + (int64_t)h->cell0 * h->C;
+    // two launch classes only: each launch is as long as its largest ring's workgroup, so more classes mostly add tails
+    for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int kcap) {
+        const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)((2 * kcap + 4) & ~3) * CSTP);
+        const int nsplit = std::min(8, std::max(1, ((lcap + 15) / 16 + 15) / 16));       // 8 waves x 2 row tiles per workgroup pass
+#define DFT_INVP(ST)                                                                                                                 \
+        {                                                                                                                            \
+            auto kern = k_rl_inverse_dft_planes<ST>;                                                                                 \
+            HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(kern, dim3(nr, nsplit, pgs.ng), dim3(512), lds, h->stream, a, planes_of<ST>(h->d_phys, h->V, h->N),   \
+                               h->d_phi, h->d_L, h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->K2,      \
+                               h->nrings, h->N, h->C, pgs, r0, lcap);                                                                \
+        }
+        if (h->f32) DFT_INVP(float) else DFT_INVP(double)
+#undef DFT_INVP
+        HIPCHK3(hipGetLastError());
+    }, 2);
+}
+
 void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
     const int id = timer_id(h, "k_rl_inverse");
     timer_begin(h, id);
+    if (dft_planes(h)) {
+        launch_rl_inverse_dft_planes(h, d_mask == h->d_mask_full);
+        timer_end(h);
+        return;
+    }
     const double *az = h->has_z ? h->d_Az : h->d_A + (int64_t)h->cell0 * h->C;
     const int64_t azrow = h->has_z ? (int64_t)h->V * 3 * h->nz * h->K2 : h->C;
     for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int kcap) {
@@ -284,14 +448,19 @@ void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
 void launch_fl_forward_dft(sx_handle *h) {
     const int id = timer_id(h, "k_fl_forward");
     timer_begin(h, id);
+    const int planes = dft_planes(h) ? 1 : 0;
     for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int) {
         const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)LCH * CST);
-        dim3 g((h->nz + DZC - 1) / DZC, h->V, nr);
+        // planes: one column tile per wave, the ring's (2 kmax + 2) / 16 tiles spread over gridDim.y workgroups of 8 waves
+        const int ntw = planes ? 1 : NTW;
+        int kcap = 0;
+        for (int i = r0; i < r0 + nr; i++) kcap = std::max(kcap, h->hkmax[i]);
+        dim3 g(planes ? 1 : (h->nz + DZC - 1) / DZC, planes ? ((2 * kcap + 2 + 15) / 16 + 7) / 8 : h->V, nr);
         HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fl_forward_dft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_fl_forward_dft, g, dim3(512), lds, h->stream, h->d_np1, h->d_Fl, h->d_L, h->d_kmax, h->d_pstart,
-                           h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N, r0, lcap);
+                           h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N, r0, lcap, planes, ntw);
         HIPCHK3(hipGetLastError());
-    });
+    }, planes ? 2 : 4);
     timer_end(h);
 }
 
