@@ -102,8 +102,8 @@ def cpu_baseline(workload, sample_cells, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="rlz_513x256x64", choices=sorted(WORKLOADS))
     ap.add_argument("--exchange", default="a2a", choices=["a2a", "gather"],
                     help="multi-GPU patch solve: transposed all-to-all (default) or the reference's halo + gather protocol")
@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
 
+    # dmabuf IPC for RCCL / cross-process device buffers; must be in the environment before the HIP runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import scythe_jl_amd as S
 
@@ -134,7 +136,6 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
