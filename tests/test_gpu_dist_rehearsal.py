@@ -63,3 +63,29 @@ def test_two_ranks_one_gpu(exchange):
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert max(res.values()) < 1e-10
+
+
+@pytest.mark.gpu
+def test_bench_cli_two_ranks_on_one_device():
+    """The driver's launch line for N = 2 (torch.distributed.run, one rank per process) with the gloo rehearsal switches:
+    bench.py must print one JSON line with the contract's keys, n_gpus = 2 and a finite state."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--workload", "rlz_small", "--backend", "gloo", "--one-device"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["nan"] is False
+    assert d["config"]["exchange"] == "a2a" and "cpu_baseline" not in d
