@@ -102,3 +102,42 @@ def test_config4_full_size_forward_transform_is_linear():
     bx, by, bxy = fwd(x), fwd(y), fwd(2.0 * x - 3.0 * y)
     assert np.abs(bxy - (2.0 * bx - 3.0 * by)).max() <= 1e-12 * np.abs(bxy).max()
     run.close()
+
+
+def test_config4_full_size_node_space_path_equals_ring_wise_path(monkeypatch):
+    """The node-space ("radial last") inverse + cell-wise equation-set kernel against the ring-wise kernels on the whole
+    513 x 256 x 64 grid: same fields after 3 steps to rounding."""
+    a = _bench_model(1)
+    monkeypatch.setenv("SX_NODE_MODE", "0")
+    b = _bench_model(1)
+    for _ in range(3):
+        a.step()
+        b.step()
+    fa, fb = a.tiles[0].var_np1, b.tiles[0].var_np1
+    for v in range(fa.shape[1]):
+        assert np.abs(fa[:, v] - fb[:, v]).max() <= 1e-11 * max(np.abs(fb[:, v]).max(), 1e-300)
+    a.close()
+    b.close()
+
+
+def test_config4_full_size_azimuthal_derivative_slots_are_the_spectral_derivatives():
+    """tileTransform! at full size: on every sampled ring and level, the d/dlambda and d2/dlambda2 slots equal the
+    FFT derivatives (numpy, on the host) of the value slot - the three slots come from one spectrum."""
+    run = _bench_model(1)
+    g = run.tiles[0]
+    g.tileTransform_()
+    phys = g.physical                                    # [N, V, D] with D = u, r, rr, l, ll, z, zz
+    L, nz = 256, 64
+    k = np.fft.rfftfreq(L, 1.0 / L)
+    for ring in (0, 7, 130, 512):
+        for z in (0, 31, 63):
+            for v in (0, 2, 4):
+                idx = (ring * L + np.arange(L)) * nz + z
+                u = phys[idx, v, 0]
+                spec = np.fft.rfft(u)
+                dl = np.fft.irfft(1j * k * spec, L)
+                dll = np.fft.irfft(-(k ** 2) * spec, L)
+                scale = max(np.abs(u).max(), 1e-300)
+                assert np.abs(phys[idx, v, 3] - dl).max() <= 1e-9 * max(np.abs(dl).max(), scale)
+                assert np.abs(phys[idx, v, 4] - dll).max() <= 1e-8 * max(np.abs(dll).max(), scale)
+    run.close()
