@@ -510,7 +510,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         h->hmask_full = full; h->hmask_eq = eq;
         if (!upload(h, &h->d_mask_full, full) || !upload(h, &h->d_mask_eq, eq)) FAIL();
         // node-space ("radial last") inverse: uniform power-of-two rings + the MFMA HRBL kernel
-        if (h->eq == SX_EQ_ONEWAY_SW_HRBL && h->V == 6 && fft_path_ok(h) && h->has_z && (h->nz == 64 || h->nz == 32) &&
+        if (h->eq == SX_EQ_ONEWAY_SW_HRBL && h->V == 6 && fft_path_ok(h) && h->has_z && (h->nz == 64 || h->nz == 32 || h->nz == 128) &&
             !(getenv("SX_NODE_MODE") && atoi(getenv("SX_NODE_MODE")) == 0)) {
             h->node_mode = 1;
             h->R_in = 0;

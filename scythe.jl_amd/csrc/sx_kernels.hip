@@ -1039,7 +1039,10 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     constexpr int CS = NZ + 2;
     constexpr int NCOL = 3 * LAM, NT = (NCOL + 15) / 16;
     __shared__ double X[3][NT * 16 * CS];
-    __shared__ double Y[3][NT * 16 * CS];
+    // results of the column operators; at zDim = 128 they wait in the accumulators and are written over X (64 KB of static LDS)
+    constexpr bool ALIAS = (NZ > 64);
+    __shared__ double Ysep[ALIAS ? 1 : 3][ALIAS ? 1 : NT * 16 * CS];
+    double (*Y)[NT * 16 * CS] = ALIAS ? X : reinterpret_cast<double (*)[NT * 16 * CS]>(&Ysep[0][0]);
     __shared__ double s1[2][NCOL];
     const int k = threadIdx.x % NZ, ll = threadIdx.x / NZ;
     const int nlb = a.L / LAM;
@@ -1116,24 +1119,44 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         constexpr int RT = NZ / 16, NW = LAM * NZ / 64;
-        for (int unit = wave; unit < RT * NT; unit += NW) {
-            const int rt = unit % RT, nt = unit / RT;
-            const int64_t ao = (int64_t)(lane >> 4) * NZ + rt * 16 + (lane & 15);      // MT[j][k] = M[k][j]
-            double ai[NZ / 4], ad[NZ / 4];
+        constexpr int UPW = (RT * NT + NW - 1) / NW;         // (row tile, column tile) units per wave
+        constexpr int KC = (NZ / 4 > 16) ? 8 : NZ / 4;       // operator fragments fetched per chunk (register budget)
+        mfma_d4 c0[UPW], c1[UPW], c2[UPW];
 #pragma unroll
-            for (int ks = 0; ks < NZ / 4; ks++) { ai[ks] = a.MintT[ao + (int64_t)ks * 4 * NZ]; ad[ks] = a.MdzT[ao + (int64_t)ks * 4 * NZ]; }
-            const int xo = (nt * 16 + (lane & 15)) * CS + (lane >> 4);
-            mfma_d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, c2 = c0;
+        for (int uu = 0; uu < UPW; uu++) {
+            const int unit = wave + uu * NW;
+            c0[uu] = mfma_d4{0.0, 0.0, 0.0, 0.0}; c1[uu] = c0[uu]; c2[uu] = c0[uu];
+            if (unit < RT * NT) {
+                const int rt = unit % RT, nt = unit / RT;
+                const int64_t ao = (int64_t)(lane >> 4) * NZ + rt * 16 + (lane & 15);      // MT[j][k] = M[k][j]
+                const int xo = (nt * 16 + (lane & 15)) * CS + (lane >> 4);
+                for (int kc = 0; kc < NZ / 4; kc += KC) {
+                    double ai[KC], ad[KC];
 #pragma unroll
-            for (int ks = 0; ks < NZ / 4; ks++) {
-                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[ks], X[0][xo + ks * 4], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], X[1][xo + ks * 4], c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], X[2][xo + ks * 4], c2, 0, 0, 0);
+                    for (int ks = 0; ks < KC; ks++) {
+                        ai[ks] = a.MintT[ao + (int64_t)(kc + ks) * 4 * NZ];
+                        ad[ks] = a.MdzT[ao + (int64_t)(kc + ks) * 4 * NZ];
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KC; ks++) {
+                        c0[uu] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[ks], X[0][xo + (kc + ks) * 4], c0[uu], 0, 0, 0);
+                        c1[uu] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], X[1][xo + (kc + ks) * 4], c1[uu], 0, 0, 0);
+                        c2[uu] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[ks], X[2][xo + (kc + ks) * 4], c2[uu], 0, 0, 0);
+                    }
+                }
             }
-            const int yo = (nt * 16 + (lane & 15)) * CS + rt * 16 + (lane >> 4);
-            Y[0][yo] = c0[0]; Y[0][yo + 4] = c0[1]; Y[0][yo + 8] = c0[2]; Y[0][yo + 12] = c0[3];
-            Y[1][yo] = c1[0]; Y[1][yo + 4] = c1[1]; Y[1][yo + 8] = c1[2]; Y[1][yo + 12] = c1[3];
-            Y[2][yo] = c2[0]; Y[2][yo + 4] = c2[1]; Y[2][yo + 8] = c2[2]; Y[2][yo + 12] = c2[3];
+        }
+        if (ALIAS) __syncthreads();
+#pragma unroll
+        for (int uu = 0; uu < UPW; uu++) {
+            const int unit = wave + uu * NW;
+            if (unit < RT * NT) {
+                const int rt = unit % RT, nt = unit / RT;
+                const int yo = (nt * 16 + (lane & 15)) * CS + rt * 16 + (lane >> 4);
+                Y[0][yo] = c0[uu][0]; Y[0][yo + 4] = c0[uu][1]; Y[0][yo + 8] = c0[uu][2]; Y[0][yo + 12] = c0[uu][3];
+                Y[1][yo] = c1[uu][0]; Y[1][yo + 4] = c1[uu][1]; Y[1][yo + 8] = c1[uu][2]; Y[1][yo + 12] = c1[uu][3];
+                Y[2][yo] = c2[uu][0]; Y[2][yo + 4] = c2[uu][1]; Y[2][yo + 8] = c2[uu][2]; Y[2][yo + 12] = c2[uu][3];
+            }
         }
     }
     __syncthreads();
@@ -1341,9 +1364,12 @@ static void launch_physics_t(sx_handle *h, int t, int part) {
             if (h->nz == 64) {
                 constexpr int LAM = 4;
                 hipLaunchKernelGGL((k_phys_hrbl_cell<64, LAM, ST>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 64), 0, h->stream, a, h->R_in / MUBAR);
-            } else {
+            } else if (h->nz == 32) {
                 constexpr int LAM = 8;
                 hipLaunchKernelGGL((k_phys_hrbl_cell<32, LAM, ST>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 32), 0, h->stream, a, h->R_in / MUBAR);
+            } else {
+                constexpr int LAM = 2;
+                hipLaunchKernelGGL((k_phys_hrbl_cell<128, LAM, ST>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 128), 0, h->stream, a, h->R_in / MUBAR);
             }
             HIPCHK(hipGetLastError());
             timer_end(h);

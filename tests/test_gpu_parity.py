@@ -82,9 +82,20 @@ def test_rlz_hrbl_mfma_column_operators(zDim):
     assert _run(cases.rlz_hrbl(num_cells=3, zDim=zDim, ring_L=16), 3) < TOL
 
 
-def test_node_space_inverse_equals_ring_wise_inverse(monkeypatch):
+def test_rlz_hrbl_node_space_at_128_levels():
+    """zDim 128 (config 5's column length): cell-wise kernel with 2 azimuths x 128 levels per workgroup, results of the
+    column operators written over their inputs in LDS."""
+    case = cases.rlz_hrbl(num_cells=6, zDim=128, ring_L=16)
+    case["ts"] = 0.05
+    assert _run(case, 3) < TOL
+
+
+@pytest.mark.parametrize("zDim,ring_L", [(32, 32), (128, 16)])
+def test_node_space_inverse_equals_ring_wise_inverse(monkeypatch, zDim, ring_L):
     """Same model with the node-space path switched off (SX_NODE_MODE=0): fields agree to rounding."""
-    case = cases.rlz_hrbl(num_cells=8, zDim=32, ring_L=32)
+    case = cases.rlz_hrbl(num_cells=8, zDim=zDim, ring_L=ring_L)
+    if zDim >= 128:
+        case["ts"] = 0.05
     a = cases.HipModel(case)
     monkeypatch.setenv("SX_NODE_MODE", "0")
     b = cases.HipModel(case)
