@@ -6,10 +6,14 @@
 // v_mfma_f64_16x16x4_f64 runs at the vector fp64 rate on MI355X, what it buys here is that one generated twiddle tile
 // serves 16 levels (and up to three derivative planes) instead of one fused multiply-add.
 //
-//   inverse  x[l][z] = sum_j T[l][j] C[j][z]      T[l][0] = 1, T[l][2k-1] = cos(2 pi k l / L), T[l][2k] = -sin(...)
-//            C = radial evaluation of Az (4 nodes), phase reference, factor 2 (same staging as k_rl_inverse)
-//            d/dlambda and d2/dlambda2 use the same T with C' = i k C and C'' = -k^2 C formed while loading B
-//   forward  F[z][j] = (1/L) sum_l X[z][l] T'[l][j]   T'[l][2k] = cos, T'[l][2k+1] = -sin  (blk indexing of Fl)
+// The ring's mirror symmetry halves the work: with theta = 2 pi / L, cos(k theta (L - l)) = cos(k theta l) and
+// sin(k theta (L - l)) = -sin(k theta l), so only the points l = 0 .. L/2 are transformed, in a cosine and a sine part,
+// and ONE twiddle (cos, sin)(k theta l) fetched per lane feeds both parts:
+//   inverse  P[l] = sum_k Cc[k] cos(k theta l),  Q[l] = sum_k Cs[k] sin(k theta l)      x[l] = P - Q,  x[L - l] = P + Q
+//            (Cc, Cs) = radial evaluation of Az (4 nodes), phase reference, factor 2 (same staging as k_rl_inverse);
+//            d/dlambda: (Cc, Cs) -> (-k Cs, k Cc);  d2/dlambda2: -k^2 (Cc, Cs), formed while loading the B operand
+//   forward  sr[k] = sum_{l <= L/2} (x[l] + x[L-l]) cos(k theta l),  si[k] = -sum (x[l] - x[L-l]) sin(k theta l)
+//            (the end points l = 0, L/2 enter once), then the phase reference and 1 / L
 //
 // Rings with fewer than 8 levels (RL grids) stay on the scalar kernels of sx_kernels.hip: the MFMA N dimension is the
 // vertical level.
@@ -31,21 +35,35 @@ constexpr int DZC = 16;       // levels per workgroup = MFMA N
 constexpr int CST = 17;       // row stride (doubles) of the LDS tiles: 4 consecutive rows land in different banks
 
 // ------------------------------------------------------------------------------------------------ inverse
+// One row-tile pair of the half ring: rows l0 / l1 (clamped), angle index m = (k l) mod L advancing by 4 l per K step.
+struct RowPair {
+    int m0, m1, s0, s1;
+    __device__ __forceinline__ void init(int l0, int l1, int kk, int L) {
+        m0 = (int)(((int64_t)kk * l0) % L); m1 = (int)(((int64_t)kk * l1) % L);
+        s0 = (int)(((int64_t)4 * l0) % L); s1 = (int)(((int64_t)4 * l1) % L);
+    }
+    __device__ __forceinline__ void step(int L) {
+        m0 += s0; if (m0 >= L) m0 -= L;
+        m1 += s1; if (m1 >= L) m1 -= L;
+    }
+};
+
 template <class ST>
 __global__ void __launch_bounds__(512)
 k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi, const int *__restrict__ Lr,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
                  const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
                  int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow, int s_u, int s_r, int s_rr, int s_l, int s_ll,
-                 int s_z, int s_zz, const int *__restrict__ slotmask, int ring0, int lcap) {
+                 int s_z, int s_zz, const int *__restrict__ slotmask, int ring0, int lcap, int kcap4) {
     extern __shared__ double sm[];
     const int ring = ring0 + blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * DZC;
     const int mask = slotmask[v];
     const int zc = min(DZC, nz - z0);
-    const int L = Lr[ring], km = kmaxr[ring];
-    const int J4 = (2 * km + 1 + 3) & ~3;                       // coefficient rows, padded to the MFMA K step
+    const int L = Lr[ring], km = kmaxr[ring], Lh = L / 2;
+    const int K4 = (km + 1 + 3) & ~3;                           // wavenumber rows 0..km, padded to the MFMA K step
     double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]   (cos, sin)(2 pi m / L)
-    double *C = sm + 2 * (size_t)lcap;                          // [J4][CST]
+    double *Cc = sm + 2 * (size_t)lcap;                         // [K4][CST] cosine coefficients
+    double *Cs = Cc + (size_t)kcap4 * CST;                      // [K4][CST] sine coefficients (row 0 = 0)
     const int j0 = ring / MUBAR;
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
@@ -63,10 +81,10 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
         const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
         const double f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
         __syncthreads();                                        // the previous set has been consumed (and twl is complete)
-        for (int e = tid; e < DZC * (km + 1); e += blockDim.x) {
-            const int k = e % (km + 1), zz = e / (km + 1);
+        for (int e = tid; e < DZC * K4; e += blockDim.x) {
+            const int k = e % K4, zz = e / K4;
             double cr = 0.0, ci = 0.0;
-            if (zz < zc) {
+            if (zz < zc && k <= km) {
                 const double *a = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + zz)) * K2;
                 if (k == 0) {
                     cr = f0 * a[0] + f1 * a[azrow] + f2 * a[2 * azrow] + f3 * a[3 * azrow];
@@ -80,72 +98,85 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                     cr = 2.0 * tr;
                 }
             }
-            if (k == 0) C[zz] = cr;
-            else { C[(2 * k - 1) * CST + zz] = cr; C[(2 * k) * CST + zz] = ci; }
+            Cc[k * CST + zz] = cr;
+            Cs[k * CST + zz] = ci;
         }
-        for (int e = tid; e < (J4 - (2 * km + 1)) * DZC; e += blockDim.x)           // zero the padding rows
-            C[(2 * km + 1 + e / DZC) * CST + (e % DZC)] = 0.0;
         __syncthreads();
 
         const int i = lane & 15, kk = lane >> 4;
-        const bool is_cos = kk & 1;
-        // two row tiles per pass: the B operands (and their derivative factors) are read once for both, and the two
-        // accumulator chains are independent, so the matrix pipe is not left waiting on a single dependent chain
-        for (int mt = wave; mt * 16 < L; mt += 2 * nw) {
+        // two row tiles of the half ring per pass: B operands (and their derivative factors) are read once for both
+        for (int mt = wave; mt * 16 <= Lh; mt += 2 * nw) {
             const int mtb = mt + nw;
-            const bool two = mtb * 16 < L;
-            const int l0 = min(mt * 16 + i, L - 1), l1 = min(mtb * 16 + i, L - 1);     // padded rows repeat the last point
-            // this lane's A column: j = 4 js + kk  ->  wavenumber k = (j + 1) / 2; its angle index m = (k l) mod L
-            int k = (kk + 1) >> 1;
-            int m0 = (int)(((int64_t)k * l0) % L), m1 = (int)(((int64_t)k * l1) % L);
-            int s0 = 2 * l0, s1 = 2 * l1;
-            if (s0 >= L) s0 -= L;
-            if (s1 >= L) s1 -= L;
-            dft_d4 au0 = {0.0, 0.0, 0.0, 0.0}, al0 = au0, all0 = au0, au1 = au0, al1 = au0, all1 = au0;
-            for (int js = 0; js < J4 / 4; js++) {
-                const double2 t0 = twl[m0], t1 = twl[m1];
-                double a0 = is_cos ? t0.x : -t0.y, a1 = is_cos ? t1.x : -t1.y;
-                if (js == 0 && kk == 0) { a0 = 1.0; a1 = 1.0; }
-                const int j = 4 * js + kk;
-                const double bu = C[j * CST + i];
+            const bool two = mtb * 16 <= Lh;
+            RowPair rp;
+            rp.init(min(mt * 16 + i, Lh), min(mtb * 16 + i, Lh), kk, L);
+            dft_d4 z4 = {0.0, 0.0, 0.0, 0.0};
+            dft_d4 pu0 = z4, qu0 = z4, pl0 = z4, ql0 = z4, pll0 = z4, qll0 = z4;
+            dft_d4 pu1 = z4, qu1 = z4, pl1 = z4, ql1 = z4, pll1 = z4, qll1 = z4;
+            double kd = (double)kk;                             // this lane's wavenumber k = 4 js + kk
+            for (int js = 0; js < K4 / 4; js++) {
+                const double2 t0 = twl[rp.m0], t1 = twl[rp.m1];
+                const double bc = Cc[(4 * js + kk) * CST + i], bs = Cs[(4 * js + kk) * CST + i];
                 if (need0) {
-                    au0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bu, au0, 0, 0, 0);
-                    if (two) au1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bu, au1, 0, 0, 0);
+                    pu0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, pu0, 0, 0, 0);
+                    qu0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, qu0, 0, 0, 0);
+                    if (two) {
+                        pu1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.x, bc, pu1, 0, 0, 0);
+                        qu1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.y, bs, qu1, 0, 0, 0);
+                    }
                 }
-                if (needl) {
-                    // i k (cr + i ci) = -k ci + i k cr: the cos row takes -k * (its sin partner), the sin row k * (its cos partner)
-                    const double bp = (j == 0 || j > 2 * km) ? 0.0 : (is_cos ? -(double)k * C[(j + 1) * CST + i] : (double)k * C[(j - 1) * CST + i]);
-                    al0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bp, al0, 0, 0, 0);
-                    if (two) al1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bp, al1, 0, 0, 0);
+                if (needl) {                                    // i k (cr + i ci): cosine part -k ci, sine part k cr
+                    const double blc = -kd * bs, bls = kd * bc;
+                    pl0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, blc, pl0, 0, 0, 0);
+                    ql0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bls, ql0, 0, 0, 0);
+                    if (two) {
+                        pl1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.x, blc, pl1, 0, 0, 0);
+                        ql1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.y, bls, ql1, 0, 0, 0);
+                    }
                 }
                 if (needll) {
-                    const double bq = -((double)k * k) * bu;
-                    all0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bq, all0, 0, 0, 0);
-                    if (two) all1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bq, all1, 0, 0, 0);
+                    const double k2 = -(kd * kd);
+                    pll0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, k2 * bc, pll0, 0, 0, 0);
+                    qll0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, k2 * bs, qll0, 0, 0, 0);
+                    if (two) {
+                        pll1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.x, k2 * bc, pll1, 0, 0, 0);
+                        qll1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.y, k2 * bs, qll1, 0, 0, 0);
+                    }
                 }
-                k += 2;
-                m0 += s0;
-                if (m0 >= L) m0 -= L;
-                m1 += s1;
-                if (m1 >= L) m1 -= L;
+                kd += 4.0;
+                rp.step(L);
             }
-            // D tile: lane holds column n = lane & 15 (level), rows (lane >> 4) + 4 r (ring points)
+            // D tile: lane holds column n = lane & 15 (level), rows (lane >> 4) + 4 r (points l of the half ring);
+            // x[l] = P - Q and, for 0 < l < L/2, x[L - l] = P + Q
             if (i < zc) {
+                auto put = [&](int slot, int64_t pt, double val) {
+                    if (slot == 0) phys.val[(int64_t)v * N + pt] = val;
+                    else phys.der[((int64_t)(slot - 1) * V + v) * N + pt] = (ST)val;
+                };
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     if (half == 1 && !two) break;
-                    const dft_d4 &au = half ? au1 : au0, &al = half ? al1 : al0, &all_ = half ? all1 : all0;
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int lo = (half ? mtb : mt) * 16 + kk + 4 * r;
-                        if (lo >= L) continue;
-                        const int64_t pt = (p0 + lo) * nz + z0 + i;
+                        if (lo > Lh) continue;
+                        const bool mirror = lo > 0 && lo < Lh;
+                        const int64_t pa = (p0 + lo) * nz + z0 + i, pb = (p0 + (L - lo)) * nz + z0 + i;
                         if (need0) {
-                            if (slot0 == 0) phys.val[(int64_t)v * N + pt] = au[r];
-                            else phys.der[((int64_t)(slot0 - 1) * V + v) * N + pt] = (ST)au[r];
+                            const double P = half ? pu1[r] : pu0[r], Q = half ? qu1[r] : qu0[r];
+                            put(slot0, pa, P - Q);
+                            if (mirror) put(slot0, pb, P + Q);
                         }
-                        if (needl) phys.der[((int64_t)(s_l - 1) * V + v) * N + pt] = (ST)al[r];
-                        if (needll) phys.der[((int64_t)(s_ll - 1) * V + v) * N + pt] = (ST)all_[r];
+                        if (needl) {
+                            const double P = half ? pl1[r] : pl0[r], Q = half ? ql1[r] : ql0[r];
+                            put(s_l, pa, P - Q);
+                            if (mirror) put(s_l, pb, P + Q);
+                        }
+                        if (needll) {
+                            const double P = half ? pll1[r] : pll0[r], Q = half ? qll1[r] : qll0[r];
+                            put(s_ll, pa, P - Q);
+                            if (mirror) put(s_ll, pb, P + Q);
+                        }
                     }
                 }
             }
@@ -156,7 +187,7 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
 // ------------------------------------------------------------------------------------------------ inverse, RL grids
 // Without a vertical dimension the MFMA columns are the requested (variable, derivative plane) pairs of the ring (19 for the
 // shallow-water slab sets): all coefficient sets - value, d/dr, d2/dr2 by radial evaluation, d/dlambda, d2/dlambda2 by
-// i k / -k^2 - are formed once while staging, so one generated twiddle tile serves every plane.
+// i k / -k^2 - are formed once while staging, so one fetched twiddle serves every plane.
 struct PlaneCols {
     int n;                    // columns in use (<= 16: one MFMA column tile per pass)
     int v[16], slot[16];      // column -> variable, derivative slot
@@ -170,24 +201,25 @@ __global__ void __launch_bounds__(512)
 k_rl_inverse_dft_planes(const double *__restrict__ A, Planes<ST> phys, const double *__restrict__ phi, const int *__restrict__ Lr,
                         const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
                         const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
-                        int K2, int nrings, int64_t N, int64_t arow, PlaneGroups pgs, int ring0, int lcap) {
+                        int K2, int nrings, int64_t N, int64_t arow, PlaneGroups pgs, int ring0, int lcap, int kcap4) {
     extern __shared__ double sm[];
     const PlaneCols &pc = pgs.g[blockIdx.z];
     // one ring has too little work per plane to fill the chip with a workgroup per ring (300 rings at config 2): the ring's
-    // row tiles are split over gridDim.y workgroups, each staging the (small) coefficient tile for itself
+    // row tiles are split over gridDim.y workgroups, each staging the (small) coefficient tiles for itself
     const int ring = ring0 + blockIdx.x;
     const int part = blockIdx.y, nparts = gridDim.y;
-    const int L = Lr[ring], km = kmaxr[ring];
-    if (part * (int)(blockDim.x >> 6) * 16 >= L) return;        // nothing for this part (uniform for the workgroup)
-    const int J4 = (2 * km + 1 + 3) & ~3;
+    const int L = Lr[ring], km = kmaxr[ring], Lh = L / 2;
+    if (part * (int)(blockDim.x >> 6) * 16 > Lh) return;        // nothing for this part (uniform for the workgroup)
+    const int K4 = (km + 1 + 3) & ~3;
     double2 *twl = reinterpret_cast<double2 *>(sm);
-    double *C = sm + 2 * (size_t)lcap;                          // [J4][CSTP]
+    double *Cc = sm + 2 * (size_t)lcap;                         // [K4][CSTP]
+    double *Cs = Cc + (size_t)kcap4 * CSTP;
     const int j0 = ring / MUBAR;
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
-    for (int e = tid; e < J4 * CSTP; e += blockDim.x) C[e] = 0.0;
+    for (int e = tid; e < K4 * CSTP; e += blockDim.x) { Cc[e] = 0.0; Cs[e] = 0.0; }
     __syncthreads();
     const double *pf = phi + (int64_t)ring * 4;
     for (int e = tid; e < V * (km + 1); e += blockDim.x) {
@@ -206,7 +238,6 @@ k_rl_inverse_dft_planes(const double *__restrict__ A, Planes<ST> phys, const dou
                 cr[d] = 2.0 * tr;
             }
         }
-        const int rr_ = (k == 0) ? 0 : 2 * k - 1, ri_ = 2 * k;      // rows of the cos / -sin coefficient
 #pragma unroll
         for (int kind = 0; kind < 5; kind++) {
             const int c = pc.colof[v][kind];
@@ -215,56 +246,57 @@ k_rl_inverse_dft_planes(const double *__restrict__ A, Planes<ST> phys, const dou
             if (kind < 3) { xr = cr[kind]; xi = ci[kind]; }
             else if (kind == 3) { xr = -(double)k * ci[0]; xi = (double)k * cr[0]; }
             else { xr = -((double)k * k) * cr[0]; xi = -((double)k * k) * ci[0]; }
-            C[rr_ * CSTP + c] = xr;
-            if (k > 0) C[ri_ * CSTP + c] = xi;
+            Cc[k * CSTP + c] = xr;
+            Cs[k * CSTP + c] = xi;
         }
     }
     __syncthreads();
     const int i = lane & 15, kk = lane >> 4;
-    const bool is_cos = kk & 1;
-    for (int mt = part * nw + wave; mt * 16 < L; mt += 2 * nw * nparts) {
+    for (int mt = part * nw + wave; mt * 16 <= Lh; mt += 2 * nw * nparts) {
         const int mtb = mt + nw * nparts;
-        const bool two = mtb * 16 < L;
-        const int l0 = min(mt * 16 + i, L - 1), l1 = min(mtb * 16 + i, L - 1);
-        int k = (kk + 1) >> 1;
-        int m0 = (int)(((int64_t)k * l0) % L), m1 = (int)(((int64_t)k * l1) % L);
-        int s0 = 2 * l0, s1 = 2 * l1;
-        if (s0 >= L) s0 -= L;
-        if (s1 >= L) s1 -= L;
-        dft_d4 a00 = {0.0, 0.0, 0.0, 0.0}, a10 = a00;                            // the two row tiles
-        for (int js = 0; js < J4 / 4; js++) {
-            const double2 t0 = twl[m0], t1 = twl[m1];
-            double a0 = is_cos ? t0.x : -t0.y, a1 = is_cos ? t1.x : -t1.y;
-            if (js == 0 && kk == 0) { a0 = 1.0; a1 = 1.0; }
-            const double b0 = C[(4 * js + kk) * CSTP + i];
-            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, a00, 0, 0, 0);
-            if (two) a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, a10, 0, 0, 0);
-            m0 += s0;
-            if (m0 >= L) m0 -= L;
-            m1 += s1;
-            if (m1 >= L) m1 -= L;
+        const bool two = mtb * 16 <= Lh;
+        RowPair rp;
+        rp.init(min(mt * 16 + i, Lh), min(mtb * 16 + i, Lh), kk, L);
+        dft_d4 p0a = {0.0, 0.0, 0.0, 0.0}, q0a = p0a, p1a = p0a, q1a = p0a;
+        for (int js = 0; js < K4 / 4; js++) {
+            const double2 t0 = twl[rp.m0], t1 = twl[rp.m1];
+            const double bc = Cc[(4 * js + kk) * CSTP + i], bs = Cs[(4 * js + kk) * CSTP + i];
+            p0a = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, p0a, 0, 0, 0);
+            q0a = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, q0a, 0, 0, 0);
+            if (two) {
+                p1a = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.x, bc, p1a, 0, 0, 0);
+                q1a = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.y, bs, q1a, 0, 0, 0);
+            }
+            rp.step(L);
         }
+        if (i >= pc.n) continue;
+        const int vv = pc.v[i], sl = pc.slot[i];
+        auto put = [&](int64_t pt, double val) {
+            if (sl == 0) phys.val[(int64_t)vv * N + pt] = val;
+            else phys.der[((int64_t)(sl - 1) * V + vv) * N + pt] = (ST)val;
+        };
 #pragma unroll
         for (int half = 0; half < 2; half++) {
-            if ((half && !two) || i >= pc.n) continue;
-            const dft_d4 &acc = half ? a10 : a00;
-            const int vv = pc.v[i], sl = pc.slot[i];
+            if (half && !two) break;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int lo = (half ? mtb : mt) * 16 + kk + 4 * r;
-                if (lo >= L) continue;
-                if (sl == 0) phys.val[(int64_t)vv * N + p0 + lo] = acc[r];
-                else phys.der[((int64_t)(sl - 1) * V + vv) * N + p0 + lo] = (ST)acc[r];
+                if (lo > Lh) continue;
+                const double P = half ? p1a[r] : p0a[r], Q = half ? q1a[r] : q0a[r];
+                put(p0 + lo, P - Q);
+                if (lo > 0 && lo < Lh) put(p0 + L - lo, P + Q);
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-// Workgroup = (16 levels, variable, ring).  The ring's points are staged LCH at a time as X[l][level]; wave w owns the
-// wavenumber tiles nt = w, w + nw, ... (16 columns j each, at most NTW per wave) and keeps their accumulators across chunks.
-constexpr int LCH = 256;      // ring points per staged chunk
-constexpr int NTW = 5;        // column tiles per wave: 8 waves x 5 x 16 = 640 columns >= 2 kmax + 2 for kmax <= 319
+// Workgroup = (16 rows, variable, ring); rows = vertical levels, or (planes) the variables of a grid without z.  The half
+// ring's points are staged LCH at a time as Xs[l][row] = x[l] + x[L-l] and Xd[l][row] = x[l] - x[L-l]; wave w owns the
+// wavenumber tiles nt = w, w + nw, ... (16 wavenumbers each, at most NTW per wave) and keeps their cosine / sine accumulators
+// across chunks.  Re and Im of a wavenumber end in the same lane, so the result is stored as 16-byte pairs.
+constexpr int LCH = 128;      // half-ring points per staged chunk
+constexpr int NTW = 3;        // wavenumber tiles per wave: 8 waves x 3 x 16 = 384 wavenumbers > kmax <= 319
 
 __global__ void __launch_bounds__(512)
 k_fl_forward_dft(const double *__restrict__ np1, double *__restrict__ Fl, const int *__restrict__ Lr,
@@ -276,76 +308,77 @@ k_fl_forward_dft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     extern __shared__ double sm[];
     const int ring = ring0 + blockIdx.z, v = planes ? 0 : blockIdx.y, z0 = planes ? 0 : blockIdx.x * DZC;
     const int zc = planes ? V : min(DZC, nz - z0);
-    const int L = Lr[ring], km = kmaxr[ring];
-    const int J = 2 * km + 2;                                   // columns: blk 0 (k = 0), blk 1 (padding), Re / Im of k >= 1
+    const int L = Lr[ring], km = kmaxr[ring], Lh = L / 2;
     double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]
-    double *X = sm + 2 * (size_t)lcap;                          // [LCH][CST]
+    double *Xs = sm + 2 * (size_t)lcap;                         // [LCH][CST]
+    double *Xd = Xs + (size_t)LCH * CST;
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    // planes mode: the ring's wavenumber tiles are split over gridDim.y workgroups (a workgroup per ring would leave most
+    // of the chip idle on RL grids); tile of (wave, q) = (part * ntw + q) * nw + wave, part = 0 otherwise
+    const int tile0 = planes ? (int)blockIdx.y * ntw * nw : 0;      // ntw <= NTW wavenumber tiles per wave
+    if (tile0 * 16 > km) return;
     for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
     const int n = lane & 15, kk = lane >> 4;
-    // planes mode: the ring's column tiles are split over gridDim.y workgroups (a workgroup per ring would leave most of
-    // the chip idle on RL grids); tile of (wave, q) = (part * ntw + q) * nw + wave, part = 0 otherwise
-    const int tile0 = planes ? (int)blockIdx.y * ntw * nw : 0;      // ntw <= NTW column tiles per wave
-    if (tile0 * 16 >= J) return;
-    dft_d4 acc[NTW];
+    dft_d4 ac[NTW], as[NTW];
 #pragma unroll
-    for (int q = 0; q < NTW; q++) acc[q] = dft_d4{0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < NTW; q++) { ac[q] = dft_d4{0.0, 0.0, 0.0, 0.0}; as[q] = ac[q]; }
     const double *x = planes ? np1 + p0 : np1 + (int64_t)v * N + p0 * nz + z0;
     const int64_t sl = planes ? 1 : nz, szz = planes ? N : 1;        // strides of a ring point / of a row in var_np1
 
-    for (int lc = 0; lc < L; lc += LCH) {
-        const int ln = min(LCH, L - lc);                        // multiple of 4 (L is)
+    for (int lc = 0; lc <= Lh; lc += LCH) {
+        const int ln = min(LCH, Lh + 1 - lc);                   // points lc .. lc + ln - 1 of the half ring
+        const int ln4 = (ln + 3) & ~3;
         __syncthreads();
-        for (int o = tid; o < ln * DZC; o += blockDim.x) {
-            const int zz = o & (DZC - 1), l = o >> 4;
-            X[l * CST + zz] = (zz < zc) ? x[(int64_t)(lc + l) * sl + zz * szz] : 0.0;
+        for (int o = tid; o < ln4 * DZC; o += blockDim.x) {
+            const int zz = o & (DZC - 1), l = lc + (o >> 4);
+            double a = 0.0, b = 0.0;
+            if (zz < zc && l <= Lh) {
+                a = x[(int64_t)l * sl + zz * szz];
+                if (l > 0 && l < Lh) b = x[(int64_t)(L - l) * sl + zz * szz];
+            }
+            Xs[(o >> 4) * CST + zz] = a + b;
+            Xd[(o >> 4) * CST + zz] = (l > 0 && l < Lh) ? a - b : 0.0;
         }
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NTW; q++) {
             const int nt = tile0 + wave + q * nw;
-            if (q >= ntw || nt * 16 >= J) continue;
-            // this lane's B column: j = nt * 16 + n -> wavenumber k = j / 2 (cos for even j, -sin for odd j)
-            const int j = nt * 16 + n;
-            const int k = min(j >> 1, km);
-            const bool is_cos = !(j & 1);
-            int m = (int)(((int64_t)k * (lc + kk)) % L);        // angle index of (k, l = lc + kk); advances by 4 k per step
-            int fourk = 4 * k;
-            while (fourk >= L) fourk -= L;
-            for (int ls = 0; ls < ln; ls += 4) {
+            if (q >= ntw || nt * 16 > km) continue;
+            // this lane's B column: wavenumber k = nt * 16 + n; angle index of (k, l = lc + kk), advancing by 4 k per step
+            const int k = min(nt * 16 + n, km);
+            int m = (int)(((int64_t)k * (lc + kk)) % L);
+            const int fourk = (int)(((int64_t)4 * k) % L);
+            for (int ls = 0; ls < ln4; ls += 4) {
                 const double2 t = twl[m];
-                const double b = is_cos ? t.x : -t.y;
-                const double a = X[(ls + kk) * CST + n];        // A tile: row = level (lane & 15), column = ring point
-                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+                ac[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(ls + kk) * CST + n], t.x, ac[q], 0, 0, 0);
+                as[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xd[(ls + kk) * CST + n], t.y, as[q], 0, 0, 0);
                 m += fourk;
                 if (m >= L) m -= L;
             }
         }
     }
-    // D tile: lane holds column n (= j within the tile), rows kk + 4 r (levels).  (Re, Im) of a wavenumber sit in
-    // neighbouring lanes: rotate by the ring's phase reference e^{-i k off} and scale by 1 / L
+    // D tile: lane holds column n (wavenumber of the tile), rows kk + 4 r.  sr = ac, si = -as; phase reference e^{-i k off}
     const double inv = 1.0 / L;
 #pragma unroll
     for (int q = 0; q < NTW; q++) {
         const int nt = tile0 + wave + q * nw;
-        if (q >= ntw || nt * 16 >= J) continue;
-        const int j = nt * 16 + n;
-        const int k = j >> 1;
-        const double2 w = phr[min(k, km)];
+        if (q >= ntw || nt * 16 > km) continue;
+        const int k = nt * 16 + n;
+        if (k > km) continue;
+        const double2 w = phr[k];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const double mine = acc[q][r];
-            const double other = __shfl_xor(mine, 1);           // partner column (j ^ 1) of the same level
             const int zz = kk + 4 * r;
-            double out;
-            if (j == 0) out = mine * inv;
-            else if (j == 1) out = 0.0;
-            else if (!(j & 1)) out = (mine * w.x + other * w.y) * inv;      // Re: sr w.x + si w.y
-            else out = (mine * w.x - other * w.y) * inv;                    // Im: si w.x - sr w.y
+            if (zz >= zc) continue;
+            const double sr = ac[q][r], si = -as[q][r];
+            double2 out;
+            if (k == 0) out = make_double2(sr * inv, 0.0);
+            else out = make_double2((sr * w.x + si * w.y) * inv, (si * w.x - sr * w.y) * inv);
             // Fl [ring][v][z][blk]: row zz is level z0 + zz of variable v, or (planes) variable zz of a grid with nz = 1
-            if (j < J && zz < zc) Fl[(planes ? (int64_t)ring * V + zz : ((int64_t)ring * V + v) * nz + z0 + zz) * K2 + j] = out;
+            double *dst = Fl + (planes ? (int64_t)ring * V + zz : ((int64_t)ring * V + v) * nz + z0 + zz) * K2 + 2 * k;
+            *reinterpret_cast<double2 *>(dst) = out;
         }
     }
 }
@@ -400,15 +433,16 @@ static void launch_rl_inverse_dft_planes(sx_handle *h, bool full) {
     const double *a = h->d_A + (int64_t)h->cell0 * h->C;
     // two launch classes only: each launch is as long as its largest ring's workgroup, so more classes mostly add tails
     for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int kcap) {
-        const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)((2 * kcap + 4) & ~3) * CSTP);
-        const int nsplit = std::min(8, std::max(1, ((lcap + 15) / 16 + 15) / 16));       // 8 waves x 2 row tiles per workgroup pass
+        const int kcap4 = (kcap + 1 + 3) & ~3;
+        const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)2 * kcap4 * CSTP);
+        const int nsplit = std::min(8, std::max(1, ((lcap / 2 + 16) / 16 + 15) / 16));      // 8 waves x 2 row tiles of the half ring per pass
 #define DFT_INVP(ST)                                                                                                                 \
         {                                                                                                                            \
             auto kern = k_rl_inverse_dft_planes<ST>;                                                                                 \
             HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL(kern, dim3(nr, nsplit, pgs.ng), dim3(512), lds, h->stream, a, planes_of<ST>(h->d_phys, h->V, h->N),   \
                                h->d_phi, h->d_L, h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->K2,      \
-                               h->nrings, h->N, h->C, pgs, r0, lcap);                                                                \
+                               h->nrings, h->N, h->C, pgs, r0, lcap, kcap4);                                                                \
         }
         if (h->f32) DFT_INVP(float) else DFT_INVP(double)
 #undef DFT_INVP
@@ -427,7 +461,8 @@ void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
     const double *az = h->has_z ? h->d_Az : h->d_A + (int64_t)h->cell0 * h->C;
     const int64_t azrow = h->has_z ? (int64_t)h->V * 3 * h->nz * h->K2 : h->C;
     for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int kcap) {
-        const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)((2 * kcap + 4) & ~3) * CST);
+        const int kcap4 = (kcap + 1 + 3) & ~3;
+        const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)2 * kcap4 * CST);
         dim3 g((h->nz + DZC - 1) / DZC, h->V, nr);
 #define DFT_INV(ST)                                                                                                                  \
         {                                                                                                                            \
@@ -436,7 +471,7 @@ void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
             hipLaunchKernelGGL(kern, g, dim3(512), lds, h->stream, az, planes_of<ST>(h->d_phys, h->V, h->N), h->d_phi, h->d_L,       \
                                h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2,         \
                                h->nrings, h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5],       \
-                               h->slot[6], d_mask, r0, lcap);                                                                        \
+                               h->slot[6], d_mask, r0, lcap, kcap4);                                                                        \
         }
         if (h->f32) DFT_INV(float) else DFT_INV(double)
 #undef DFT_INV
@@ -450,12 +485,12 @@ void launch_fl_forward_dft(sx_handle *h) {
     timer_begin(h, id);
     const int planes = dft_planes(h) ? 1 : 0;
     for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int) {
-        const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)LCH * CST);
-        // planes: one column tile per wave, the ring's (2 kmax + 2) / 16 tiles spread over gridDim.y workgroups of 8 waves
+        const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)2 * LCH * CST);
+        // planes: one wavenumber tile per wave, the ring's (kmax + 1) / 16 tiles spread over gridDim.y workgroups of 8 waves
         const int ntw = planes ? 1 : NTW;
         int kcap = 0;
         for (int i = r0; i < r0 + nr; i++) kcap = std::max(kcap, h->hkmax[i]);
-        dim3 g(planes ? 1 : (h->nz + DZC - 1) / DZC, planes ? ((2 * kcap + 2 + 15) / 16 + 7) / 8 : h->V, nr);
+        dim3 g(planes ? 1 : (h->nz + DZC - 1) / DZC, planes ? ((kcap + 1 + 15) / 16 + 7) / 8 : h->V, nr);
         HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fl_forward_dft), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_fl_forward_dft, g, dim3(512), lds, h->stream, h->d_np1, h->d_Fl, h->d_L, h->d_kmax, h->d_pstart,
                            h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N, r0, lcap, planes, ntw);
