@@ -800,7 +800,6 @@ int sx_spectral_transform(sx_handle *h) {
     if (!h) { set_error("null handle"); return 1; }
     launch_fl_forward(h);
     launch_sb(h);
-    launch_zf(h);
     return status();
 }
 
@@ -835,7 +834,6 @@ int sx_advance(sx_handle *h, int32_t t) {
     launch_inverse_and_physics(h, t);
     launch_fl_forward(h);
     launch_sb(h);
-    launch_zf(h);
     return status();
 }
 
@@ -1056,7 +1054,6 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     else if (k == "k_fl_forward") b = w * (N * V + fl);
     else if (k == "k_sb") b = w * (fl + bz);
     else if (k == "k_sbz") b = w * (fl + S_tile);
-    else if (k == "k_zf") b = w * (bz + S_tile);
     else if (k == "k_solve") b = w * 4.0 * S_patch;                 // read B, write y, read y, write A
     else if (k == "k_semiimplicit") b = w * N * 2.0 * 5.0;
     *bytes = b;

@@ -168,7 +168,6 @@ void launch_inverse_and_physics(sx_handle *h, int t);
 void launch_copy_slot0(sx_handle *h);
 void launch_fl_forward(sx_handle *h);
 void launch_sb(sx_handle *h);
-void launch_zf(sx_handle *h);
 void launch_solve(sx_handle *h);
 void launch_solve_a2a(sx_handle *h, const double *recv, double *send);
 void launch_a2a_pack(sx_handle *h, double *buf, int unpack);

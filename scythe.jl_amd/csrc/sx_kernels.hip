@@ -1462,7 +1462,7 @@ void launch_fl_forward(sx_handle *h) {
 }
 
 void launch_sb(sx_handle *h) {
-    if (h->has_z) {        // fused with the vertical forward transform; launch_zf is then a no-op
+    if (h->has_z) {        // fused with the vertical forward transform
         const int id = timer_id(h, "k_sbz");
         timer_begin(h, id);
         if (h->nz == 64 || h->nz == 32 || h->nz == 128) {
@@ -1496,8 +1496,6 @@ void launch_sb(sx_handle *h) {
     timer_end(h);
 }
 
-// the vertical forward transform is fused into k_sbz / k_sbw (launch_sb)
-void launch_zf(sx_handle *) {}
 
 void launch_solve(sx_handle *h) {
     const int id = timer_id(h, "k_solve");
