@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, exchange, q):
+def _worker(rank, world, port, exchange, q, case_kw=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,7 +29,7 @@ def _worker(rank, world, port, exchange, q):
         import scythe_jl_amd as S
         from tests import cases
         torch.cuda.set_device(0)
-        case = cases.rlz_hrbl(num_cells=8, zDim=12, ring_L=32)
+        case = cases.rlz_hrbl(**(case_kw or dict(num_cells=8, zDim=12, ring_L=32)))
         gp, mp_ = cases.hip_params(case)
         run = S.ModelRun(mp_, num_tiles=world, rank=rank, device=torch.device("cuda", 0), use_dist=True, exchange=exchange)
         tile = run.tiles[0]
@@ -62,6 +62,23 @@ def test_two_ranks_one_gpu(exchange):
         p.join(300)
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
+    assert max(res.values()) < 1e-10
+
+
+def test_four_ranks_one_gpu_uneven_tiles_node_space_path():
+    """Four ranks (the most a GPU box lets share one card with headroom), 14 cells -> tiles of 4, 4, 3, 3 cells, 32 levels
+    on uniform rings: rank 0 runs ring-wise, the others partly or wholly through the node-space inverse."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    kw = dict(num_cells=14, zDim=32, ring_L=16)
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, "a2a", q, kw)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(4))
     assert max(res.values()) < 1e-10
 
 
