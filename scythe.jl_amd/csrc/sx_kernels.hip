@@ -1052,6 +1052,22 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     const double g = par[SX_P_G], Kh = par[SX_P_KH], Hfree = par[SX_P_HFREE], f = par[SX_P_F];
     const int64_t gp = ((int64_t)cell * a.L + lam) * NZ + k;
     const int64_t gs = (int64_t)a.L * NZ;
+    // per-ring constants of the final phase (phi, phi', phi'' weights and 1 / r) go through LDS once, so that the three ring
+    // passes after the column operators do not each wait for their own scalar loads
+    __shared__ double sphi[MUBAR][12], srinv[MUBAR];
+    if (threadIdx.x < MUBAR * 12) {
+        const int mu = threadIdx.x / 12, e = threadIdx.x % 12;
+        sphi[mu][e] = a.phi[((int64_t)(e / 4) * a.nrings + cell * MUBAR + mu) * 4 + (e % 4)];
+    } else if (threadIdx.x < MUBAR * 13) {
+        const int mu = threadIdx.x - MUBAR * 12;
+        srinv[mu] = 1.0 / a.r[(int64_t)(cell * MUBAR + mu) * a.L];
+    }
+    // the surface-drag lanes (k < 3: one ring each) fetch their cos / sin(lambda) now, with everything else
+    double cs_d = 0.0, sn_d = 0.0;
+    if (k < MUBAR) {
+        const int64_t col = (int64_t)(cell * MUBAR + k) * a.L + lam;
+        cs_d = a.cosl[col]; sn_d = a.sinl[col];
+    }
     // node transforms: [transform][node]
     double qh[4], qhl[4], qug[4], qugl[4], qvg[4], qvgl[4];
     double qub[4], qubl[4], qubll[4], qubz[4], qvb[4], qvbl[4], qvbll[4], qvbz[4];
@@ -1097,14 +1113,12 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
         if (k == 1) { s1[0][c] = ub; s1[1][c] = DOT(w0, qvb); }
     }
     __syncthreads();
-    HIST(1)
     if (k < MUBAR) {       // surface drag replaces the level-0 flux (src/shallowWaterModels.jl:463-482); lane k takes ring k
         const double Um = par[SX_P_UM], Vm = par[SX_P_VM];
         {
             const int mu = k;
-            const int64_t col = (int64_t)(cell * MUBAR + mu) * a.L + lam;
             const int c = mu * LAM + ll;
-            const double cs = a.cosl[col], sn = a.sinl[col];
+            const double cs = cs_d, sn = sn_d;
             const double sfcu = (Um * cs) + (Vm * sn), sfcv = (Vm * cs) - (Um * sn);
             const double u10 = s1[0][c] + sfcu, v10 = s1[1][c] + sfcv;
             const double U10 = sqrt(u10 * u10 + v10 * v10);
@@ -1115,6 +1129,7 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
             X[2][c * CS] = Cd * U10 * v10;
         }
     }
+    HIST(1)                // in flight during the column operators
     __syncthreads();
     {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1162,11 +1177,10 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     __syncthreads();
 #pragma unroll
     for (int mu = 0; mu < MUBAR; mu++) {
-        const int ring = cell * MUBAR + mu;
         const int64_t p = pc + mu * gs;
         if (mu == 0) { HIST(2) }
-        const double *w0 = a.phi + (int64_t)ring * 4, *w1 = w0 + (int64_t)a.nrings * 4, *w2 = w1 + (int64_t)a.nrings * 4;
-        const double ri = 1.0 / a.r[(int64_t)ring * a.L], ri2 = ri * ri;
+        const double *w0 = sphi[mu], *w1 = sphi[mu] + 4, *w2 = sphi[mu] + 8;
+        const double ri = srinv[mu], ri2 = ri * ri;
         const double h = DOT(w0, qh), hr = DOT(w1, qh), hl = DOT(w0, qhl);
         const double ug = DOT(w0, qug), ugr = DOT(w1, qug), ugl = DOT(w0, qugl);
         const double vg = DOT(w0, qvg), vgr = DOT(w1, qvg), vgl = DOT(w0, qvgl);
@@ -1362,7 +1376,7 @@ static void launch_physics_t(sx_handle *h, int t, int part) {
             a.col0 = split; a.col1 = h->Nh;
             const int ncell = (h->nrings - h->R_in) / MUBAR;         // R_in is a multiple of 3 (sx_create)
             if (h->nz == 64) {
-                constexpr int LAM = 4;
+                constexpr int LAM = 4;      // 2: 0.55 ms (6 of 16 MFMA columns, 1 KB chunks); 4: 0.41 ms
                 hipLaunchKernelGGL((k_phys_hrbl_cell<64, LAM, ST>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 64), 0, h->stream, a, h->R_in / MUBAR);
             } else if (h->nz == 32) {
                 constexpr int LAM = 8;
