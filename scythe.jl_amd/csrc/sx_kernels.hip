@@ -932,6 +932,8 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
     // tendency history of the five prognostic variables: fetched now so that its HBM latency overlaps the load phase
     // (with one 1024-thread workgroup per CU nothing else would hide it at the end of the kernel)
     double e1h[5] = {0, 0, 0, 0, 0}, e2h[5] = {0, 0, 0, 0, 0};
+    double cs_d = 0.0, sn_d = 0.0;      // cos / sin(lambda) of the surface-drag lane, fetched with everything else
+    if (live && k == 0) { cs_d = a.cosl[col]; sn_d = a.sinl[col]; }
     if (live) {
 #pragma unroll
         for (int v = 0; v < 5; v++) {
@@ -957,7 +959,7 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
     __syncthreads();
     if (live && k == 0) {
         const double Um = par[SX_P_UM], Vm = par[SX_P_VM];
-        const double cs = a.cosl[col], sn = a.sinl[col];
+        const double cs = cs_d, sn = sn_d;
         const double sfcu = (Um * cs) + (Vm * sn), sfcv = (Vm * cs) - (Um * sn);
         const double u10 = s1[0][cl] + sfcu, v10 = s1[1][cl] + sfcv;
         const double U10 = sqrt(u10 * u10 + v10 * v10);
