@@ -417,13 +417,21 @@ __device__ __forceinline__ S2 operator*(double c, S2 a) { return S2{c * a.x, c *
 __device__ __forceinline__ S1 zero(S1 *) { return S1{0.0}; }
 __device__ __forceinline__ S2 zero(S2 *) { return S2{0.0, 0.0}; }
 
+// row m of the right-hand side from the LDS offset table: first source + (second source if the global table has one)
+template <class T>
+__device__ __forceinline__ T brow2(const double *__restrict__ B, const int64_t *sofs, const int64_t *__restrict__ ob, int m, int64_t col) {
+    const T x = ld(B + sofs[m * 4 + 0] + col, (T *)nullptr), y = ld(B + sofs[m * 4 + 1] + col, (T *)nullptr);
+    return x + (sofs[m * 4 + 1] != sofs[m * 4 + 0] ? 1.0 : 0.0) * y;
+}
+
 template <class T>
 __device__ __forceinline__ T brow(const double *__restrict__ B, const int64_t *__restrict__ oa, const int64_t *__restrict__ ob,
                                   int m, int64_t col) {
-    T x = ld(B + oa[m] + col, (T *)nullptr);
-    const int64_t o2 = ob[m];
-    if (o2 >= 0) x = x + ld(B + o2 + col, (T *)nullptr);
-    return x;
+    // branch-free: a row without a second source re-reads the first one and adds nothing (a branch per row would keep the
+    // compiler from batching the loads of a block of rows)
+    const int64_t o1 = oa[m], o2 = ob[m];
+    const T x = ld(B + o1 + col, (T *)nullptr), y = ld(B + (o2 >= 0 ? o2 : o1) + col, (T *)nullptr);
+    return x + (o2 >= 0 ? 1.0 : 0.0) * y;
 }
 
 // Row m of the right-hand side is Bsrc[boffA[m] + col] (+ Bsrc[boffB[m] + col] where a second tile overlaps, boffB >= 0);
@@ -435,22 +443,39 @@ __device__ __forceinline__ void solve_columns(const double *__restrict__ Bsrc, c
                                               const int *__restrict__ cmeta, const double *__restrict__ gl,
                                               const double *__restrict__ gr, const double *__restrict__ Lband,
                                               const double *__restrict__ Ldinv, const double *__restrict__ Larrow, int nb, int c,
-                                              int64_t col, int64_t stride) {
+                                              int64_t col, int64_t stride, bool active) {
     const int n = cmeta[c * 4 + 0], per = cmeta[c * 4 + 1], rl = cmeta[c * 4 + 2], rr = cmeta[c * 4 + 3];
     const double *Lb = Lband + (int64_t)c * nb * 4;
     const double *Ld = Ldinv + (int64_t)c * nb;
+    // The factor rows (l0, l1, l2, 1 / diagonal) of this boundary-condition class go to LDS once per workgroup: as scalar
+    // loads from memory they could not be fetched a batch ahead (16 rows x 5 doubles exceed the scalar registers), and
+    // every couple of rows waited ~500 cycles for its own scalar load - the whole run time of the kernel.
+    extern __shared__ double sfac[];              // [nb][4] factor rows, then (not LINEAR) [nb][4] row offsets
+    int64_t *sofs = reinterpret_cast<int64_t *>(sfac + (size_t)nb * 4);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const double4 l4 = *reinterpret_cast<const double4 *>(Lb + (int64_t)e * 4);
+        *reinterpret_cast<double4 *>(sfac + (size_t)e * 4) = make_double4(l4.x, l4.y, l4.z, Ld[e]);
+    }
+    if (!LINEAR)
+        for (int e = threadIdx.x; e < nb; e += blockDim.x) {
+            const int64_t o1 = boffA[e], o2 = boffB[e], a1 = aoffA[e], a2 = aoffB[e];
+            // no second source / destination: repeat the first (its contribution is masked, the store is idempotent)
+            sofs[e * 4 + 0] = o1; sofs[e * 4 + 1] = o2 >= 0 ? o2 : o1; sofs[e * 4 + 2] = a1; sofs[e * 4 + 3] = a2 >= 0 ? a2 : a1;
+        }
+    __syncthreads();
+    if (!active) return;
     const double *La = Larrow + (int64_t)c * 3 * nb;
     const double *g_l = gl + c * 6, *g_r = gr + c * 6;
     T *tp = nullptr;
     // LINEAR: one contiguous [row][col] array on each side (row offset = m * stride), no offset tables to fetch
-#define BROW(m) (LINEAR ? ld(Bsrc + (int64_t)(m) * stride + col, tp) : brow<T>(Bsrc, boffA, boffB, (m), col))
-#define AROW(m) ld(A + (LINEAR ? (int64_t)(m) * stride : aoffA[m]) + col, tp)
-#define ASET(m, val) st(A + (LINEAR ? (int64_t)(m) * stride : aoffA[m]) + col, (val))
+#define BROW(m) (LINEAR ? ld(Bsrc + (int64_t)(m) * stride + col, tp) : brow2<T>(Bsrc, sofs, boffB, (m), col))
+#define AROW(m) ld(A + (LINEAR ? (int64_t)(m) * stride : sofs[(m) * 4 + 2]) + col, tp)
+#define ASET(m, val) st(A + (LINEAR ? (int64_t)(m) * stride : sofs[(m) * 4 + 2]) + col, (val))
 #define AFIN(m, val)                                                     \
     do {                                                                 \
         const T v_ = (val);                                              \
-        st(A + (LINEAR ? (int64_t)(m) * stride : aoffA[m]) + col, v_);   \
-        if (!LINEAR && aoffB[m] >= 0) st(A + aoffB[m] + col, v_);        \
+        st(A + (LINEAR ? (int64_t)(m) * stride : sofs[(m) * 4 + 2]) + col, v_);   \
+        if (!LINEAR) st(A + sofs[(m) * 4 + 3] + col, v_);   /* no second destination: the same address again */ \
     } while (0)
     if (!per) {
         // forward substitution; the free unknown i lives in row rl + i of A
@@ -461,49 +486,85 @@ __device__ __forceinline__ void solve_columns(const double *__restrict__ Bsrc, c
         // Full batches of SOLVE_U rows run without any control flow (row index tests are selects), so the compiler hoists the
         // wave-uniform factor loads of a whole batch in front of its dependent multiply-adds; with a branch per row every row
         // waited for its own scalar loads (~700 cycles per row, the whole kernel).  The remainder rows take the simple loop.
-        auto fwd_row = [&](int i, T s) {
-            s = s + (i == 0 ? 1.0 : 0.0) * bl0 + (i == 1 ? 1.0 : 0.0) * bl1;
-            s = s + (i == n - 1 ? 1.0 : 0.0) * br0 + (i == n - 2 ? 1.0 : 0.0) * br1;
-            const double *l = Lb + (int64_t)i * 4;
-            s = s - (l[2] * y1 + l[1] * y2 + l[0] * y3);
-            s = Ld[i] * s;
+        // interior rows: nothing but the three-term recurrence (7 multiply / add per column and row); the boundary-condition
+        // contributions only touch the first and last two rows, which take the general form outside the batches
+        auto fwd_plain = [&](int i, T s) {
+            const double4 l = *reinterpret_cast<const double4 *>(sfac + (size_t)i * 4);
+            s = s - (l.z * y1 + l.y * y2 + l.x * y3);
+            s = l.w * s;
             y3 = y2; y2 = y1; y1 = s;
             ASET(rl + i, s);
         };
-        const int nfull = (n / SOLVE_U) * SOLVE_U;
-        for (int i0 = 0; i0 < nfull; i0 += SOLVE_U) {
-            T rhs[SOLVE_U];
+        auto fwd_edge = [&](int i, T s) {
+            if (i == 0) s = s + bl0;
+            if (i == 1) s = s + bl1;
+            if (i == n - 1) s = s + br0;
+            if (i == n - 2) s = s + br1;
+            fwd_plain(i, s);
+        };
+        const int f_lo = min(2, n), f_hi = max(f_lo, n - 2);                      // interior rows [f_lo, f_hi)
+        const int f_full = f_lo + ((f_hi - f_lo) / SOLVE_U) * SOLVE_U;
+        for (int i = 0; i < f_lo; i++) fwd_edge(i, BROW(rl + i));
+        // The rows of batch b + 1 are requested BEFORE batch b is computed and stored: the memory counter of this hardware
+        // retires loads and stores in issue order, so a load issued after a batch's stores would also wait for those
+        // stores to complete (and its own latency would be exposed once per batch).
+        {
+            T rhs[SOLVE_U], nxt[SOLVE_U];
+            if (f_lo < f_full) {
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) rhs[u] = BROW(rl + i0 + u);
+                for (int u = 0; u < SOLVE_U; u++) rhs[u] = BROW(rl + f_lo + u);
+            }
+            for (int i0 = f_lo; i0 < f_full; i0 += SOLVE_U) {
+                const bool more = i0 + SOLVE_U < f_full;
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) fwd_row(i0 + u, rhs[u]);
+                for (int u = 0; u < SOLVE_U; u++) nxt[u] = BROW(rl + (more ? i0 + SOLVE_U + u : i0 + u));
+#pragma unroll
+                for (int u = 0; u < SOLVE_U; u++) fwd_plain(i0 + u, rhs[u]);
+#pragma unroll
+                for (int u = 0; u < SOLVE_U; u++) rhs[u] = nxt[u];
+            }
         }
-        for (int i = nfull; i < n; i++) fwd_row(i, BROW(rl + i));
+        for (int i = f_full; i < n; i++) fwd_edge(i, BROW(rl + i));
         // back substitution
         T x1 = zero(tp), x2 = zero(tp), x3 = zero(tp);     // x[i+1], x[i+2], x[i+3]
         T xl0 = zero(tp), xl1 = zero(tp), xr0 = zero(tp), xr1 = zero(tp);
-        // factor rows i + 1 .. i + 3 are read unconditionally (clamped to the last row) and masked by a select
-        auto bwd_row = [&](int i, T s) {
-            const int i1 = min(i + 1, n - 1), i2 = min(i + 2, n - 1), i3 = min(i + 3, n - 1);
-            s = s - ((i + 1 < n ? Lb[(int64_t)i1 * 4 + 2] : 0.0) * x1 + (i + 2 < n ? Lb[(int64_t)i2 * 4 + 1] : 0.0) * x2 +
-                     (i + 3 < n ? Lb[(int64_t)i3 * 4 + 0] : 0.0) * x3);
+        auto bwd_plain = [&](int i, T s) {                 // rows i <= n - 4: all three super-diagonal terms exist
+            s = s - (sfac[(size_t)(i + 1) * 4 + 2] * x1 + sfac[(size_t)(i + 2) * 4 + 1] * x2 + sfac[(size_t)(i + 3) * 4 + 0] * x3);
+            s = sfac[(size_t)i * 4 + 3] * s;
+            x3 = x2; x2 = x1; x1 = s;
+            AFIN(rl + i, s);
+        };
+        auto bwd_edge = [&](int i, T s) {
+            if (i + 1 < n) s = s - Lb[(int64_t)(i + 1) * 4 + 2] * x1;
+            if (i + 2 < n) s = s - Lb[(int64_t)(i + 2) * 4 + 1] * x2;
+            if (i + 3 < n) s = s - Lb[(int64_t)(i + 3) * 4 + 0] * x3;
             s = Ld[i] * s;
             x3 = x2; x2 = x1; x1 = s;
             AFIN(rl + i, s);
-            xr0 = (i == n - 1) ? s : xr0;
-            xr1 = (i == n - 2) ? s : xr1;
-            xl1 = (i == 1) ? s : xl1;
-            xl0 = (i == 0) ? s : xl0;
+            if (i == n - 1) xr0 = s;
+            if (i == n - 2) xr1 = s;
+            if (i == 1) xl1 = s;
+            if (i == 0) xl0 = s;
         };
         int ib = n - 1;
-        for (; ib >= SOLVE_U - 1; ib -= SOLVE_U) {
-            T rhs[SOLVE_U];
+        for (; ib >= max(n - 3, 0); ib--) bwd_edge(ib, AROW(rl + ib));               // last three rows
+        {                                                                            // interior rows down to row 2
+            T rhs[SOLVE_U], nxt[SOLVE_U];
+            if (ib >= SOLVE_U + 1) {
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) rhs[u] = AROW(rl + ib - u);
+                for (int u = 0; u < SOLVE_U; u++) rhs[u] = AROW(rl + ib - u);
+            }
+            for (; ib >= SOLVE_U + 1; ib -= SOLVE_U) {
+                const bool more = ib - SOLVE_U >= SOLVE_U + 1;
 #pragma unroll
-            for (int u = 0; u < SOLVE_U; u++) bwd_row(ib - u, rhs[u]);
+                for (int u = 0; u < SOLVE_U; u++) nxt[u] = AROW(rl + (more ? ib - SOLVE_U - u : ib - u));
+#pragma unroll
+                for (int u = 0; u < SOLVE_U; u++) bwd_plain(ib - u, rhs[u]);
+#pragma unroll
+                for (int u = 0; u < SOLVE_U; u++) rhs[u] = nxt[u];
+            }
         }
-        for (; ib >= 0; ib--) bwd_row(ib, AROW(rl + ib));
+        for (; ib >= 0; ib--) bwd_edge(ib, AROW(rl + ib));
         for (int q = 0; q < rl; q++) AFIN(q, g_l[q * 2] * xl0 + g_l[q * 2 + 1] * xl1);
         for (int q = 0; q < rr; q++) AFIN(nb - 1 - q, g_r[q * 2] * xr0 + g_r[q * 2 + 1] * xr1);
     } else {
@@ -561,7 +622,10 @@ __device__ __forceinline__ void solve_columns(const double *__restrict__ Bsrc, c
 // boundary-condition class, so a lane solves both with double2 loads/stores; rows are contiguous across lanes, so every
 // access is coalesced. The k = 0 column (own class, single column) is handled by one extra block per (variable,
 // z-mode) in which only lane 0 works.
-template <bool LINEAR>
+// PAIR = false: one column per lane (twice the waves, half the dependent arithmetic per row): used when the launch has too
+// few wavenumbers to occupy the chip - the transposed solve of a multi-GPU run - where the kernel time is the latency
+// of one wave's row recurrence.
+template <bool LINEAR, bool PAIR = true>
 __global__ void __launch_bounds__(64)
 k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA, const int64_t *__restrict__ boffB,
         double *__restrict__ A, const int64_t *__restrict__ aoffA, const int64_t *__restrict__ aoffB,
@@ -571,15 +635,20 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA, cons
     const int vz = blockIdx.y;                      // local (v, zm) group; vz0 + vz is the patch-level group
     const int v = (vz0 + vz) / Zb;
     const bool k0 = (blockIdx.x == gridDim.x - 1);  // the last block in x handles the k = 0 column
+    // every lane takes part in staging the factor rows; lanes without a column leave after that (`active`)
     if (k0) {
-        if (threadIdx.x != 0) return;
         solve_columns<S1, LINEAR>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 0],
-                                  (int64_t)vz * K2, stride);
-    } else {
+                                  (int64_t)vz * K2, stride, threadIdx.x == 0);
+    } else if (PAIR) {
         const int k = 1 + blockIdx.x * 64 + threadIdx.x;      // wavenumber; its columns are blocks 2k and 2k + 1
-        if (2 * k + 1 >= K2) return;
+        const bool act = 2 * k + 1 < K2;
         solve_columns<S2, LINEAR>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 1],
-                                  (int64_t)vz * K2 + 2 * k, stride);
+                                  (int64_t)vz * K2 + (act ? 2 * k : 2), stride, act);
+    } else {
+        const int c = 2 + blockIdx.x * 64 + threadIdx.x;      // column (Re or Im of a wavenumber >= 1)
+        const bool act = c < K2;
+        solve_columns<S1, LINEAR>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 1],
+                                  (int64_t)vz * K2 + (act ? c : 2), stride, act);
     }
 }
 
@@ -1518,11 +1587,11 @@ void launch_solve(sx_handle *h) {
     timer_begin(h, id);
     dim3 g((h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1, h->V * h->Zb);
     if (h->d_Bsrc == h->d_Bfull)     // internal contiguous B: no offset tables needed
-        hipLaunchKernelGGL(k_solve<true>, g, dim3(64), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff, h->d_neg1,
+        hipLaunchKernelGGL(k_solve<true>, g, dim3(64), sizeof(double) * 4 * h->b_rDim, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff, h->d_neg1,
                            h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2, 0,
                            h->C);
     else
-        hipLaunchKernelGGL(k_solve<false>, g, dim3(64), 0, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff,
+        hipLaunchKernelGGL(k_solve<false>, g, dim3(64), sizeof(double) * 8 * h->b_rDim, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff,
                            h->d_neg1, h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb,
                            h->K2, 0, h->C);
     HIPCHK(hipGetLastError());
@@ -1536,10 +1605,13 @@ void launch_solve_a2a(sx_handle *h, const double *recv, double *send) {
     timer_begin(h, id);
     const int ng = h->a2a_g1 - h->a2a_g0;
     if (ng > 0) {
-        dim3 g((h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1, ng);
-        hipLaunchKernelGGL(k_solve<false>, g, dim3(64), 0, h->stream, recv, h->d_a2a_offA, h->d_a2a_offB, send, h->d_a2a_offA,
-                           h->d_a2a_offB, h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb,
-                           h->K2, h->a2a_g0, (int64_t)0);
+        const int bx_pair = (h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1;
+        const bool single = (int64_t)bx_pair * ng < 768 && h->K2 > 2;        // fewer waves than SIMDs: one column per lane
+#define A2A_ARGS recv, h->d_a2a_offA, h->d_a2a_offB, send, h->d_a2a_offA, h->d_a2a_offB, h->d_cls, h->d_cmeta, h->d_gl, h->d_gr,      \
+                 h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2, h->a2a_g0, (int64_t)0
+        if (single) hipLaunchKernelGGL((k_solve<false, false>), dim3((h->K2 - 2 + 63) / 64 + 1, ng), dim3(64), sizeof(double) * 8 * h->b_rDim, h->stream, A2A_ARGS);
+        else hipLaunchKernelGGL((k_solve<false, true>), dim3(bx_pair, ng), dim3(64), sizeof(double) * 8 * h->b_rDim, h->stream, A2A_ARGS);
+#undef A2A_ARGS
         HIPCHK(hipGetLastError());
     }
     timer_end(h);
