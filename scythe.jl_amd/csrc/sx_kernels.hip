@@ -1552,11 +1552,13 @@ void launch_sb(sx_handle *h) {
         timer_begin(h, id);
         if (h->nz == 64 || h->nz == 32 || h->nz == 128) {
             // cells per workgroup (+3 warm-up cells): about 1.5 workgroups per CU (one round of 2 resident workgroups; 11 at
-            // config 4, measured best of 4..12), never fewer than 6 so that the warm-up stays below half of the reads
+            // config 4, measured best of 4..12), on large tiles never fewer than 6 so that the warm-up stays below half of the reads
             const int groups = ((h->K2 + 63) / 64) * h->V;
             // zDim 128 runs one 512-thread workgroup per CU (229 VGPRs): one full round of 256 instead of 1.5 rounds of 2 x 256
             const int nseg = std::max(1, (h->nz == 128 ? 256 : 384) / groups);
-            const int cps = std::max(6, (h->ncells + nseg - 1) / nseg);
+            // small tiles (multi-GPU strong scaling): the kernel is then one workgroup's latency chain, which is proportional
+            // to the cells it walks, so short segments (down to 2 cells + 3 warm-up) beat the saved re-reads
+            const int cps = std::max(h->ncells <= 64 ? 2 : 6, (h->ncells + nseg - 1) / nseg);
             dim3 gw((h->K2 + 63) / 64, h->V, (h->ncells + cps - 1) / cps);
             auto kern = h->nz == 64 ? k_sbw<64> : h->nz == 32 ? k_sbw<32> : k_sbw<128>;
             hipLaunchKernelGGL(kern, gw, dim3(512), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->d_CB, h->ncells,
