@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the multi-rank path on a single GPU (not a performance mode)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
+    ap.add_argument("--tile-split", default="cost", choices=["cost", "reference"],
+                    help="radial partition for N > 1: 'cost' gives the inner tiles (ring-wise kernels, ~1.6x per ring) fewer "
+                         "cells; 'reference' is calcTileSizes' even split")
     ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
                     help="f32: derivative slots of `physical` stored as fp32 (config 5; not the headline metric, whose "
                          "1e-10 parity bar needs fp64 throughout)")
@@ -146,7 +149,7 @@ def main():
     mp = S.ModelParameters(ts=TS_OF.get(args.workload, TS), equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
                            physical_params=dict(PAR))
     run = S.ModelRun(mp, num_tiles=world, rank=rank, device=torch.device("cuda", local_rank), use_dist=world > 1,
-                     exchange=args.exchange)
+                     exchange=args.exchange, split=args.tile_split)
     tile = run.tiles[0]
     pts = S.getGridpoints(tile)
     run.set_initial_conditions([initial_condition(pts)])
@@ -210,7 +213,7 @@ def main():
             "config": {"workload": "RLZ %dx%dx%d (rings x azimuth x levels), 6 vars, 7 derivative slots, "
                                    "Oneway_ShallowWater_HeightResolvedBL, uniform ring table kmax<=%d, b_zDim %d"
                                    % (3 * nc, L, nz, L // 2 - 1, int(tile.dims.b_zDim)),
-                       "num_cells": nc, "tiles": world, "exchange": run.exchange_kind, "ts": TS_OF.get(args.workload, TS), "nan": bool(nan)},
+                       "num_cells": nc, "tiles": world, "tile_cells": list(run.layout.ncells), "exchange": run.exchange_kind, "ts": TS_OF.get(args.workload, TS), "nan": bool(nan)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},

@@ -18,8 +18,16 @@ class PatchLayout:
     """Which patch rows (radial nodes) each tile computes, owns and sends (calcPatchMap / calcHaloMap,
     src/semiimplicit.jl:79-86), and where they sit in the all-gather buffer."""
 
-    def __init__(self, patch: GridParameters, num_tiles: int, n_cols: int = 0):
+    def __init__(self, patch: GridParameters, num_tiles: int, n_cols: int = 0, split="reference"):
+        """split = "reference": calcTileSizes (cells split evenly, or gridpoints balanced on native rings).
+        split = "cost" (uniform ring tables only): cells whose rings still have a growing wavenumber truncation
+        (ring index < L/2 - 1) run the ring-wise kernels, which cost about 1.6x the node-space path per ring, so the inner
+        tiles get proportionally fewer cells - the same idea as the reference's gridpoint balancing (src/semiimplicit.jl:144)."""
         ts = calcTileSizes(patch, num_tiles)
+        if split == "cost" and num_tiles > 1 and patch.ring_uniform_L > 0 and "L" in patch.geometry:
+            ts = _cost_balanced_tiles(patch, num_tiles, ts)
+        elif split not in ("reference", "cost"):
+            raise ValueError("split must be 'reference' or 'cost'")
         self.num_tiles = num_tiles
         self.ncells = [int(ts[2, t]) for t in range(num_tiles)]
         self.cell0 = [int(ts[3, t]) - 1 for t in range(num_tiles)]
@@ -42,6 +50,27 @@ class PatchLayout:
             for j in range(self.owned_rows(t)):
                 off[self.cell0[t] + j] = (t * self.max_rows + j) * n_cols
         return off
+
+
+def _cost_balanced_tiles(patch, n, ts_ref, inner_weight=1.6):
+    nc = patch.num_cells
+    kcap = patch.ring_uniform_L // 2 - 1
+    w = np.array([inner_weight if 3 * c < kcap else 1.0 for c in range(nc)])
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    bounds = [0]
+    for t in range(1, n):
+        c = int(np.searchsorted(cum, cum[-1] * t / n))
+        c = max(c, bounds[-1] + 3)                    # at least 3 cells per tile (calcTileSizes' rule)
+        c = min(c, nc - 3 * (n - t))
+        bounds.append(c)
+    bounds.append(nc)
+    DX = (patch.xmax - patch.xmin) / nc
+    pts_per_cell = 3 * patch.ring_uniform_L * max(patch.zDim, 1) if "Z" in patch.geometry else 3 * patch.ring_uniform_L
+    ts = np.zeros_like(ts_ref)
+    for t in range(n):
+        c0, c1 = bounds[t], bounds[t + 1]
+        ts[:, t] = (patch.xmin + c0 * DX, patch.xmin + c1 * DX, c1 - c0, c0 + 1, (c1 - c0) * pts_per_cell)
+    return ts
 
 
 def _torch():
@@ -212,14 +241,15 @@ class DistA2AExchange:
 class ModelRun:
     """initialize_model + run_model state for one process (src/semiimplicit.jl:126-256)."""
 
-    def __init__(self, model: ModelParameters, num_tiles=1, rank=None, device=None, use_dist=False, exchange="a2a"):
+    def __init__(self, model: ModelParameters, num_tiles=1, rank=None, device=None, use_dist=False, exchange="a2a",
+                 split="reference"):
         """exchange: "a2a" = transposed solve over all-to-all (scales), "gather" = the reference's protocol
         (halo chain + gather of owned rows + redundant patch solve on every tile)."""
         self.model = model
         patch = model.grid_params
         self.patch = patch
         self.num_tiles = num_tiles
-        self.layout = PatchLayout(patch, num_tiles)
+        self.layout = PatchLayout(patch, num_tiles, split=split)
         self.use_dist = use_dist
         if use_dist:
             t = rank

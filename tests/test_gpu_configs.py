@@ -54,23 +54,24 @@ def test_config3_rz_513x128_semiimplicit():
     _check(hip.physical(), orc.physical())
 
 
-def _bench_model(num_tiles, exchange="a2a"):
+def _bench_model(num_tiles, exchange="a2a", split="reference"):
     import bench
     import scythe_jl_amd as S
     kw, L = bench.grid_kwargs("rlz_513x256x64")
     gp = S.GridParameters(ring_uniform_L=L, **kw)
     mp = S.ModelParameters(ts=bench.TS, equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
                            physical_params=dict(bench.PAR))
-    run = S.ModelRun(mp, num_tiles=num_tiles, device="cuda", exchange=exchange)
+    run = S.ModelRun(mp, num_tiles=num_tiles, device="cuda", exchange=exchange, split=split)
     run.set_initial_conditions([bench.initial_condition(S.getGridpoints(g)) for g in run.tiles])
     return run
 
 
 def test_config4_full_size_tiling_invariance():
-    """RLZ 513 x 256 x 64, 6 variables: 3 radial tiles (transposed solve) reproduce the one-tile run."""
+    """RLZ 513 x 256 x 64, 6 variables: 3 even radial tiles and 4 cost-balanced ones (transposed solve) reproduce the
+    one-tile run."""
     fields = []
-    for nt in (1, 3):
-        run = _bench_model(nt)
+    for nt, split in ((1, "reference"), (3, "reference"), (4, "cost")):
+        run = _bench_model(nt, split=split)
         for _ in range(3):
             run.step()
         vals = []
@@ -80,10 +81,11 @@ def test_config4_full_size_tiling_invariance():
             vals.append(g.physical[:, :, 0])
         fields.append(np.concatenate(vals, axis=0))
         run.close()
-    a, b = fields
-    for v in range(a.shape[1]):
-        sc = np.abs(a[:, v]).max()
-        assert np.abs(a[:, v] - b[:, v]).max() <= 1e-11 * max(sc, 1e-300)
+    a = fields[0]
+    for b in fields[1:]:
+        for v in range(a.shape[1]):
+            sc = np.abs(a[:, v]).max()
+            assert np.abs(a[:, v] - b[:, v]).max() <= 1e-11 * max(sc, 1e-300)
 
 
 def test_config4_full_size_forward_transform_is_linear():

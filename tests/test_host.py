@@ -146,3 +146,23 @@ def test_reference_state_file_readers(tmp_path):
     g.write_text("".join("%r 1.0 1.0 1.0 0.0\n" % float(zz + 1.0) for zz in z))
     with pytest.raises(ValueError):
         S.reference_state.exact_reference_state(mp2)
+
+
+def test_cost_balanced_tile_split_for_uniform_rings():
+    """PatchLayout(split="cost"): contiguous tiles of at least 3 cells that cover the patch; tiles holding the inner
+    (ring-wise path) cells get fewer cells; native rings and split="reference" keep calcTileSizes' partition."""
+    gp = S.GridParameters(geometry="RLZ", xmin=0.0, xmax=3.0e5, num_cells=171, zmin=0.0, zmax=2.0e3, zDim=64,
+                          vars={"h": 1, "u": 2, "v": 3, "ub": 4, "vb": 5, "wb": 6}, ring_uniform_L=256)
+    for n in (2, 4, 8):
+        ref = S.PatchLayout(gp, n)
+        lay = S.PatchLayout(gp, n, split="cost")
+        assert sum(lay.ncells) == 171 and min(lay.ncells) >= 3
+        assert lay.cell0 == [sum(lay.ncells[:t]) for t in range(n)]
+        assert lay.ncells[0] < ref.ncells[0] and lay.ncells[-1] > ref.ncells[-1]
+        w = [sum(1.6 if 3 * c < 127 else 1.0 for c in range(c0, c0 + m)) for c0, m in zip(lay.cell0, lay.ncells)]
+        assert max(w) - min(w) <= 2 * 1.6 + 1e-9                    # balanced to within a cell or two
+        assert int(lay.tile_sizes[4].sum()) == 513 * 256 * 64
+    native = S.GridParameters(geometry="RL", xmin=0.0, xmax=3.0e5, num_cells=30, vars={"h": 1})
+    assert S.PatchLayout(native, 3, split="cost").ncells == S.PatchLayout(native, 3).ncells
+    with pytest.raises(ValueError):
+        S.PatchLayout(gp, 2, split="nope")
