@@ -175,7 +175,10 @@ int sx_spline_transform(sx_handle *h);
 /* tileTransform!(patchSplines, patchSpectral, gp, tile, splineBuffer) (src/semiimplicit.jl:241, 305) */
 int sx_tile_transform(sx_handle *h);
 /* advanceTimestep up to and including calcTendency (src/semiimplicit.jl:305-317):
- * tileTransform! -> equation set -> explicit_timestep [-> semiimplicit_adjustment] -> spectralTransform! */
+ * tileTransform! -> equation set -> explicit_timestep [-> semiimplicit_adjustment] -> spectralTransform!
+ * Only the derivative planes the equation set reads are produced, and on uniform rings part of them never leaves the
+ * node-space form: after sx_advance the contents of `physical` are unspecified - call sx_tile_transform (the output path,
+ * src/semiimplicit.jl:289-290) before sx_get_physical. */
 int sx_advance(sx_handle *h, int32_t t);
 /* physical_model only (src/semiimplicit.jl:357-363) on the current tile.physical */
 int sx_physics(sx_handle *h, int32_t t);

@@ -1041,15 +1041,15 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     const double fin = node ? (double)h->R_in / h->nrings : 1.0;   // fraction of rings on the ring-wise path
     if (k == "k_rl_inverse") b = (N * out_planes + w * az) * fin;   // write the requested physical planes, read Az
     else if (k == "k_node_fft") b = (double)h->NG * node_planes + w * az;
-    else if (k == "k_phys_hrbl_inner") b = N * fin * (eq_planes + w * (4.0 * V - 2.0));
+    else if (k == "k_phys_hrbl_inner") b = N * fin * (eq_planes + w * (4.0 * V - 3.0));
     else if (k == "k_phys_hrbl" && node)                            // node transforms (read once) + history + outputs
-        b = (double)h->NG * node_planes + N * (1.0 - fin) * w * (4.0 * V - 2.0);
+        b = (double)h->NG * node_planes + N * (1.0 - fin) * w * (4.0 * V - 3.0);
     else if (k == "k_zinv") b = w * (S_tile + az);
     else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") {
         // read the requested slots, E_nm1, E_nm2; write E_n, var_np1; the SW sets also write the diagnostic w plane and
         // keep no tendency history for it
         const bool sw = (h->eq == SX_EQ_ONEWAY_SW_SLAB || h->eq == SX_EQ_TWOWAY_SW_SLAB || h->eq == SX_EQ_ONEWAY_SW_HRBL);
-        b = N * (eq_planes + w * (4.0 * V + (sw ? 1.0 - 3.0 : 0.0)));
+        b = N * (eq_planes + w * (4.0 * V + (sw ? -3.0 : 0.0)));        // inside sx_advance the diagnostic w plane is not stored
     }
     else if (k == "k_fl_forward") b = w * (N * V + fl);
     else if (k == "k_sb") b = w * (fl + bz);

@@ -112,6 +112,7 @@ struct sx_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 0;
     std::vector<int> hmask_full, hmask_eq;       // host copies of d_mask_full / d_mask_eq
+    bool in_advance = false;    // set while sx_advance launches the equation set (the diagnostic w plane is then not stored)
     bool L_all_mult4 = false;   // every ring length is a multiple of 4 (native rings are): the MFMA DFT kernels apply
     double *d_ref = nullptr;    // ReferenceState [3][3][nz] (Euler_test)
     int f32 = 0;   // fp32 storage of d_Az, d_phys, d_G, d_Fl (allocated as raw bytes, typed by the launchers)

@@ -716,6 +716,8 @@ struct PhysArgsT {
     Planes<ST> G;
     const double *phi;
     const double *ref;    // ReferenceState [3][3][nz] (Euler_test)
+    int write_w;          // store the diagnostic w into physical[:, 6, 1] (src/shallowWaterModels.jl:66-67, 426-429): only the
+                          // stand-alone sx_physics needs it there; inside sx_advance nothing reads that plane again
     int64_t NG;
     int L, nrings;
 };
@@ -820,7 +822,7 @@ __global__ void k_phys_pointwise(PhysArgsT<ST> a) {
             const double vb = PSV(4), vbr = PS(4, a.s_r), vbrr = PS(4, a.s_rr), vbl = PS(4, a.s_l), vbll = PS(4, a.s_ll);
             const double U = 0.78 * sqrt((ub * ub) + (vb * vb));
             const double w = -Hb * ((ub / r) + ubr + (vbl / r));
-            a.P.val[(int64_t)5 * a.N + p] = w;
+            if (a.write_w) a.P.val[(int64_t)5 * a.N + p] = w;
             const double w_ = 0.5 * fabs(w) - w;
             double e0 = ((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)));
             if (a.eq == SX_EQ_TWOWAY_SW_SLAB) e0 += -(Hfree + h) * w * par[SX_P_S1];
@@ -951,7 +953,7 @@ __global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgsT<ST> a, int cpb) {
         vdu += md * xu[j];
         vdv += md * xv[j];
     }
-    a.P.val[(int64_t)5 * a.N + p] = wb;
+    if (a.write_w) a.P.val[(int64_t)5 * a.N + p] = wb;
     const double e0 = ((-vg * hl / r) + (-ug * hr)) + (-(Hfree + h) * ((ug / r) + ugr + (vgl / r)));
     const double e1 = ((-vg * ugl / r) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg / r)));
     const double e2 = ((-vg * vgl / r) + (-ug * vgr)) + (-g * (hl / r)) + (-ug * (f + (vg / r)));
@@ -1076,7 +1078,7 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
     __syncthreads();
     if (!live) return;
     const double wb = Y[0][cl * CS + k], vdu = Y[1][cl * CS + k], vdv = Y[2][cl * CS + k];
-    a.P.val[(int64_t)5 * a.N + p] = wb;
+    if (a.write_w) a.P.val[(int64_t)5 * a.N + p] = wb;
     const double e0 = ((-vg * hl * ri) + (-ug * hr)) + (-(Hfree + h) * ((ug * ri) + ugr + (vgl * ri)));
     const double e1 = ((-vg * ugl * ri) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg * ri)));
     const double e2 = ((-vg * vgl * ri) + (-ug * vgr)) + (-g * (hl * ri)) + (-ug * (f + (vg * ri)));
@@ -1261,7 +1263,7 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
         const double vbl = DOT(w0, qvbl), vbll = DOT(w0, qvbll), vbz = DOT(w0, qvbz);
         const int c = mu * LAM + ll;
         const double wb = Y[0][c * CS + k], vdu = Y[1][c * CS + k], vdv = Y[2][c * CS + k];
-        a.P.val[(int64_t)5 * a.N + p] = wb;
+        if (a.write_w) a.P.val[(int64_t)5 * a.N + p] = wb;
         const double e0 = ((-vg * hl * ri) + (-ug * hr)) + (-(Hfree + h) * ((ug * ri) + ugr + (vgl * ri)));
         const double e1 = ((-vg * ugl * ri) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg * ri)));
         const double e2 = ((-vg * vgl * ri) + (-ug * vgr)) + (-g * (hl * ri)) + (-ug * (f + (vg * ri)));
@@ -1406,7 +1408,7 @@ static PhysArgsT<ST> phys_args(sx_handle *h, int t) {
     a.In = h->d_I[0] ? h->d_I[h->rot % 3] : nullptr;
     a.np1 = h->d_np1;
     a.r = h->d_r; a.cosl = h->d_cosl; a.sinl = h->d_sinl; a.z = h->d_z;
-    a.MintT = h->d_MintT; a.MdzT = h->d_MdzT; a.ref = h->d_ref;
+    a.MintT = h->d_MintT; a.MdzT = h->d_MdzT; a.ref = h->d_ref; a.write_w = h->in_advance ? 0 : 1;
     a.N = h->N; a.V = h->V; a.nz = h->nz; a.t = t; a.eq = h->eq;
     a.s_u = h->slot[0]; a.s_r = h->slot[1]; a.s_rr = h->slot[2]; a.s_l = h->slot[3]; a.s_ll = h->slot[4];
     a.s_z = h->slot[5]; a.s_zz = h->slot[6];
@@ -1506,6 +1508,7 @@ void launch_physics(sx_handle *h, int t) { launch_physics_part(h, t, 0); }
 // disjoint points.  With SX_OVERLAP=1 the inner chain runs on a second (non-blocking) stream, forked after the vertical
 // inverse and joined before the forward transform (measured gain 2.6 %: off by default, see sx_internal.hpp).
 void launch_inverse_and_physics(sx_handle *h, int t) {
+    struct Scope { sx_handle *h; Scope(sx_handle *x) : h(x) { h->in_advance = true; } ~Scope() { h->in_advance = false; } } scope(h);
     const bool two = h->node_mode && h->R_in > 0 && h->overlap && h->eq == SX_EQ_ONEWAY_SW_HRBL && !h->semi;
     if (!two) {
         launch_rl_inverse(h, false);
