@@ -419,19 +419,9 @@ __device__ __forceinline__ S2 zero(S2 *) { return S2{0.0, 0.0}; }
 
 // row m of the right-hand side from the LDS offset table: first source + (second source if the global table has one)
 template <class T>
-__device__ __forceinline__ T brow2(const double *__restrict__ B, const int64_t *sofs, const int64_t *__restrict__ ob, int m, int64_t col) {
+__device__ __forceinline__ T brow2(const double *__restrict__ B, const int64_t *sofs, int m, int64_t col) {
     const T x = ld(B + sofs[m * 4 + 0] + col, (T *)nullptr), y = ld(B + sofs[m * 4 + 1] + col, (T *)nullptr);
     return x + (sofs[m * 4 + 1] != sofs[m * 4 + 0] ? 1.0 : 0.0) * y;
-}
-
-template <class T>
-__device__ __forceinline__ T brow(const double *__restrict__ B, const int64_t *__restrict__ oa, const int64_t *__restrict__ ob,
-                                  int m, int64_t col) {
-    // branch-free: a row without a second source re-reads the first one and adds nothing (a branch per row would keep the
-    // compiler from batching the loads of a block of rows)
-    const int64_t o1 = oa[m], o2 = ob[m];
-    const T x = ld(B + o1 + col, (T *)nullptr), y = ld(B + (o2 >= 0 ? o2 : o1) + col, (T *)nullptr);
-    return x + (o2 >= 0 ? 1.0 : 0.0) * y;
 }
 
 // Row m of the right-hand side is Bsrc[boffA[m] + col] (+ Bsrc[boffB[m] + col] where a second tile overlaps, boffB >= 0);
@@ -468,7 +458,7 @@ __device__ __forceinline__ void solve_columns(const double *__restrict__ Bsrc, c
     const double *g_l = gl + c * 6, *g_r = gr + c * 6;
     T *tp = nullptr;
     // LINEAR: one contiguous [row][col] array on each side (row offset = m * stride), no offset tables to fetch
-#define BROW(m) (LINEAR ? ld(Bsrc + (int64_t)(m) * stride + col, tp) : brow2<T>(Bsrc, sofs, boffB, (m), col))
+#define BROW(m) (LINEAR ? ld(Bsrc + (int64_t)(m) * stride + col, tp) : brow2<T>(Bsrc, sofs, (m), col))
 #define AROW(m) ld(A + (LINEAR ? (int64_t)(m) * stride : sofs[(m) * 4 + 2]) + col, tp)
 #define ASET(m, val) st(A + (LINEAR ? (int64_t)(m) * stride : sofs[(m) * 4 + 2]) + col, (val))
 #define AFIN(m, val)                                                     \
