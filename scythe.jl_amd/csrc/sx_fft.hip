@@ -235,7 +235,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                 auto copy_out = [&](auto *out) {
                     if (zz < zc) {
 #pragma unroll 4
-                        for (int l = threadIdx.x >> LOGZ; l < L; l += (int)(blockDim.x >> LOGZ)) out[(int64_t)l * nz + zz] = src[2 * l];
+                        for (int l = threadIdx.x >> LOGZ; l < L; l += (int)(blockDim.x >> LOGZ)) __builtin_nontemporal_store((decltype(+out[0]))src[2 * l], out + (int64_t)l * nz + zz);
                     }
                 };
                 if (slot == 0) copy_out(phys.val + (int64_t)v * N + p0 * nz + z0);

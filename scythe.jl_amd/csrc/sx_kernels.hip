@@ -1080,14 +1080,14 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
 #pragma unroll
     for (int v = 0; v < 5; v++) {          // explicit_timestep (src/semiimplicit.jl:672-698) with the prefetched history
         const int64_t o = (int64_t)v * a.N + p;
-        a.En[o] = ee[v];
+        __builtin_nontemporal_store(ee[v], a.En + o);
         double un;
         if (a.t == 1) un = uu[v] + (a.ts * ee[v]);
         else if (a.t == 2) un = uu[v] + (0.5 * a.ts) * ((3.0 * ee[v]) - e1h[v]);
         else un = uu[v] + ((a.ts / 12.0) * ((23.0 * ee[v]) - (16.0 * e1h[v]) + (5.0 * e2h[v])));
-        a.np1[o] = un;
+        __builtin_nontemporal_store(un, a.np1 + o);
     }
-    diag_step(a, 5, p, wb);
+    __builtin_nontemporal_store(wb, a.np1 + (int64_t)5 * a.N + p);
     for (int v = 6; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
 }
 
@@ -1270,9 +1270,10 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
             if (a.t == 1) un = uu[v] + (a.ts * ee[v]);
             else if (a.t == 2) un = uu[v] + (0.5 * a.ts) * ((3.0 * ee[v]) - e1h[mu][v]);
             else un = uu[v] + ((a.ts / 12.0) * ((23.0 * ee[v]) - (16.0 * e1h[mu][v]) + (5.0 * e2h[mu][v])));
-            a.np1[o] = un;
+            __builtin_nontemporal_store(un, a.np1 + o);      // 0.4 GB per step: next read by the forward transform, after
+                                                             // everything else of this kernel has gone through the caches
         }
-        diag_step(a, 5, p, wb);
+        __builtin_nontemporal_store(wb, a.np1 + (int64_t)5 * a.N + p);
     }
 #undef DOT
 #undef HIST
