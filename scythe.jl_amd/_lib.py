@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscythe_hip.so")
+# SCYTHE_HIP_LIB points at an alternative build of the same ABI (A/B timing of two builds on one box)
+LIB_PATH = os.environ.get("SCYTHE_HIP_LIB") or os.path.join(_HERE, "libscythe_hip.so")
 
 SX_ABI_VERSION = 2
 GEOM = {"R": 0, "RZ": 1, "RL": 2, "RLZ": 3}

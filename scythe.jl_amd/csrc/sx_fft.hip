@@ -281,7 +281,7 @@ k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     double *ba = (double *)smf;
     for (int o = tid; o < L * FZC; o += blockDim.x) {
         const int zz = o & (FZC - 1), l = o >> LOGZ;
-        const double val = (zz < zc) ? x[(int64_t)l * nz + zz] : 0.0;
+        const double val = (zz < zc) ? __builtin_nontemporal_load(x + (int64_t)l * nz + zz) : 0.0;
         ba[2 * ((zz >> 1) * (L + SKEW) + l) + (zz & 1)] = val;
     }
     __syncthreads();

@@ -349,7 +349,7 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
                     const double *src = base + (int64_t)ring * plane;
                     double x[ZPT];
 #pragma unroll
-                    for (int i = 0; i < ZPT; i++) x[i] = src[(int64_t)(8 * i) * K2];
+                    for (int i = 0; i < ZPT; i++) x[i] = __builtin_nontemporal_load(src + (int64_t)(8 * i) * K2);   // read once (1.3x with the warm-up cells): keep the caches for B and the history
 #pragma unroll
                     for (int i = 0; i < ZPT; i++) {
                         acc[u][i] += w0 * x[i];
@@ -998,8 +998,8 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
     if (live) {
 #pragma unroll
         for (int v = 0; v < 5; v++) {
-            if (a.t >= 2) e1h[v] = a.E1[(int64_t)v * a.N + p];
-            if (a.t >= 3) e2h[v] = a.E2[(int64_t)v * a.N + p];
+            if (a.t >= 2) e1h[v] = __builtin_nontemporal_load(a.E1 + (int64_t)v * a.N + p);
+            if (a.t >= 3) e2h[v] = __builtin_nontemporal_load(a.E2 + (int64_t)v * a.N + p);
         }
         r = a.r[col];
         ri = 1.0 / r;
