@@ -1411,7 +1411,8 @@ static PhysArgsT<ST> phys_args(sx_handle *h, int t) {
 
 // History rotation replaces the copies of explicit_timestep: after step t the buffer written as expdot_n becomes
 // expdot_nm1 and the previous nm1 becomes nm2. rot decreases by one (mod 3) per step.
-constexpr int PCPB = 16;      // columns per workgroup of the MFMA HRBL kernel (8: two resident workgroups, measured slower)
+constexpr int PCPB = 8;       // columns per workgroup of the ring-wise MFMA HRBL kernel: two resident 512-thread workgroups per CU
+                              // (A/B on one box: 0.146 ms vs 0.154 ms with 16 columns / one workgroup per CU)
 
 template <class ST>
 static void launch_physics_t(sx_handle *h, int t, int part) {
