@@ -399,7 +399,7 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
 // A wave covers 64 consecutive wavenumber blocks of one (variable, z-mode): its boundary-condition class is
 // wave-uniform, so the factor entries are scalar loads. The k = 0 column (its own class) is handled by one extra
 // block per (variable, z-mode) in which only lane 0 works.
-#define SOLVE_U 16
+#define SOLVE_U 8
 // scalar / pair arithmetic so that one kernel body serves a lane that owns one column (k = 0) or the (Re, Im) pair of a
 // wavenumber (two independent right-hand sides moved as one 16-byte access)
 struct S1 { double x; };
