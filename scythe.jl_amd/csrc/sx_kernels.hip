@@ -399,7 +399,6 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
 // A wave covers 64 consecutive wavenumber blocks of one (variable, z-mode): its boundary-condition class is
 // wave-uniform, so the factor entries are scalar loads. The k = 0 column (its own class) is handled by one extra
 // block per (variable, z-mode) in which only lane 0 works.
-#define SOLVE_U 8
 // scalar / pair arithmetic so that one kernel body serves a lane that owns one column (k = 0) or the (Re, Im) pair of a
 // wavenumber (two independent right-hand sides moved as one 16-byte access)
 struct S1 { double x; };
@@ -426,7 +425,9 @@ __device__ __forceinline__ T brow2(const double *__restrict__ B, const int64_t *
 
 // Row m of the right-hand side is Bsrc[boffA[m] + col] (+ Bsrc[boffB[m] + col] where a second tile overlaps, boffB >= 0);
 // row m of the solution goes to A[aoffA[m] + col] and, in the final sweep, also to A[aoffB[m] + col] if aoffB >= 0.
-template <class T, bool LINEAR>
+// SOLVE_U rows per batch: 8 when the launch fills the chip (single-tile solve: bandwidth-bound, A/B 750 -> 755 steps/s),
+// 16 for the transposed multi-GPU solve, whose few waves are latency-bound (8 there: 0.058 -> 0.098 ms)
+template <class T, bool LINEAR, int SOLVE_U>
 __device__ __forceinline__ void solve_columns(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA,
                                               const int64_t *__restrict__ boffB, double *__restrict__ A,
                                               const int64_t *__restrict__ aoffA, const int64_t *__restrict__ aoffB,
@@ -615,7 +616,7 @@ __device__ __forceinline__ void solve_columns(const double *__restrict__ Bsrc, c
 // PAIR = false: one column per lane (twice the waves, half the dependent arithmetic per row): used when the launch has too
 // few wavenumbers to occupy the chip - the transposed solve of a multi-GPU run - where the kernel time is the latency
 // of one wave's row recurrence.
-template <bool LINEAR, bool PAIR = true>
+template <bool LINEAR, bool PAIR = true, int SOLVE_U = LINEAR ? 8 : 16>
 __global__ void __launch_bounds__(64)
 k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA, const int64_t *__restrict__ boffB,
         double *__restrict__ A, const int64_t *__restrict__ aoffA, const int64_t *__restrict__ aoffB,
@@ -627,17 +628,17 @@ k_solve(const double *__restrict__ Bsrc, const int64_t *__restrict__ boffA, cons
     const bool k0 = (blockIdx.x == gridDim.x - 1);  // the last block in x handles the k = 0 column
     // every lane takes part in staging the factor rows; lanes without a column leave after that (`active`)
     if (k0) {
-        solve_columns<S1, LINEAR>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 0],
+        solve_columns<S1, LINEAR, SOLVE_U>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 0],
                                   (int64_t)vz * K2, stride, threadIdx.x == 0);
     } else if (PAIR) {
         const int k = 1 + blockIdx.x * 64 + threadIdx.x;      // wavenumber; its columns are blocks 2k and 2k + 1
         const bool act = 2 * k + 1 < K2;
-        solve_columns<S2, LINEAR>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 1],
+        solve_columns<S2, LINEAR, SOLVE_U>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 1],
                                   (int64_t)vz * K2 + (act ? 2 * k : 2), stride, act);
     } else {
         const int c = 2 + blockIdx.x * 64 + threadIdx.x;      // column (Re or Im of a wavenumber >= 1)
         const bool act = c < K2;
-        solve_columns<S1, LINEAR>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 1],
+        solve_columns<S1, LINEAR, SOLVE_U>(Bsrc, boffA, boffB, A, aoffA, aoffB, cmeta, gl, gr, Lband, Ldinv, Larrow, nb, cls[v * 2 + 1],
                                   (int64_t)vz * K2 + (act ? c : 2), stride, act);
     }
 }
