@@ -224,11 +224,17 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_cells, args.cpu_steps)
             except Exception as e:   # the baseline is a reported side figure; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        if nan:
+            # a run that blew up is not a throughput measurement: no value, non-zero exit
+            out["value"] = None
+            out["error"] = "NaN in the model state after the timed steps (checkCFL)"
         print(json.dumps(out), flush=True)
     run.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if nan:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

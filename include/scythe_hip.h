@@ -186,7 +186,8 @@ int sx_physics(sx_handle *h, int32_t t);
  * sx_advance / sx_set_physical_values leaves complete; a NaN in physical[:, v, 1] always reaches it) */
 int sx_check_nan(sx_handle *h, int32_t *flag);
 /* on-device diagnostic: out[n_vars] = max |var_np1[:, v]| after the last step; with the grid spacing
- * the caller forms the advective CFL number without pulling a field to the host (NaNs are skipped: see sx_check_nan) */
+ * the caller forms the advective CFL number without pulling a field to the host.  A NaN anywhere in a variable makes its
+ * maximum NaN (like maximum(abs, x) in Julia).  No allocation per call: the scratch lives with the handle. */
 int sx_max_abs(sx_handle *h, double *out);
 
 /* --- tile <-> patch exchange on the device (src/semiimplicit.jl:320-329, 272-285) ---------------------------------- */

@@ -29,6 +29,8 @@ SQRT35 = np.sqrt(3.0 / 5.0)
 GAUSS_OFF = np.array([-SQRT35 / 2.0, 0.0, SQRT35 / 2.0])   # mish offsets inside a unit cell, centred
 QUAD_W = np.array([8.0, 5.0, 8.0]) / 21.0                  # ratio 8:5:8 pinned by the notebook KAT
 MUBAR = 3
+XP = np.longdouble            # x87 80-bit extended precision on this platform
+PI_X = 4 * np.arctan(XP(1))
 
 BC_RANK = {"R0": 0, "R1T0": 1, "R1T1": 1, "R1T2": 1, "R2T10": 2, "R2T20": 2, "R3": 3}
 R1_COEF = {"R1T0": (-4.0, -1.0), "R1T1": (0.0, 1.0), "R1T2": (2.0, -1.0)}
@@ -37,7 +39,9 @@ R1_COEF = {"R1T0": (-4.0, -1.0), "R1T1": (0.0, 1.0), "R1T2": (2.0, -1.0)}
 # ----------------------------------------------------------------------------- cubic B-spline
 def bspline(delta, d):
     """d-th derivative (w.r.t. delta) of the cardinal cubic B-spline, vectorised."""
-    delta = np.asarray(delta, dtype=np.float64)
+    delta = np.asarray(delta)
+    if delta.dtype != XP:
+        delta = delta.astype(np.float64)
     z = np.abs(delta)
     s = np.where(delta > 0, 1.0, -1.0)
     p = 2.0 - z
@@ -151,8 +155,6 @@ class Ring:
 
 
 # ----------------------------------------------------------------------------- Chebyshev column
-XP = np.longdouble            # x87 80-bit extended precision on this platform
-PI_X = 4 * np.arctan(XP(1))
 
 
 class Cheb:
@@ -228,7 +230,7 @@ class Cheb:
             proj = proj - Cm.T @ Gi @ Cm
         CAx = proj @ pad                                # b -> a
         f64 = lambda m: np.asarray(m, dtype=np.float64)
-        self._x = dict(T=Tx, Dc=Dcx, TD=TDx, TDD=TDDx)       # extended-precision factors (Helmholtz assembly)
+        self._x = dict(T=Tx, Dc=Dcx, TD=TDx, TDD=TDDx, CA=CAx, CB=CBx)   # extended-precision factors (Helmholtz assembly, inverse_xp)
         self.T, self.Dc, self.CBm, self.CAm, self.Ic = f64(Tx), f64(Dcx), f64(CBx), f64(CAx), f64(Ic)
         self.M = [f64(Tx @ CAx), f64(TDx @ CAx), f64(TDDx @ CAx)]       # b -> values, d/dz, d2/dz2
         self.Mint = f64(Tx @ Ic @ CAx)                                     # b -> integral from the bottom
@@ -445,6 +447,52 @@ class Grid:
         return phys
 
 
+def inverse_xp(grid, A, rings, cell0=0):
+    """tileTransform! for the listed patch rings in EXTENDED precision (numpy longdouble) from Float64 A coefficients and
+    Float64 gridpoints: the arbiter for "which fp64 evaluation of a derivative slot is closer to the exact one".
+    Returns {ring: phys[L * zDim, V, D]} (longdouble).  Dense and slow on purpose; pass a sample of rings."""
+    g = grid
+    sl = {s_: i for i, s_ in enumerate(g.slots)}
+    out = {}
+    xm = XP(g.xmin) + (np.arange(g.b_rDim, dtype=XP) - 1) * XP(g.DX)
+    for ring in rings:
+        c = ring // MUBAR
+        r64 = mish_points(g.xmin, g.DX, c, 1)[ring % MUBAR]                   # the Float64 gridpoint, as handed to the user
+        delta = ((XP(r64) - xm) / XP(g.DX))[None, :]
+        PH = [bspline(delta, d)[0] / XP(g.DX) ** d for d in range(3)]        # [b_rDim]
+        L, km = int(g.L[ring]), int(g.kmax[ring])
+        nb = 1 + 2 * km
+        lam = XP(g.off[ring]) + 2 * PI_X * np.arange(L, dtype=XP) / XP(L)
+        FI = [np.zeros((L, nb), dtype=XP) for _ in range(3)]
+        FI[0][:, 0] = 1
+        for k in range(1, km + 1):
+            cs, sn = np.cos(k * lam), np.sin(k * lam)
+            FI[0][:, 2 * k - 1], FI[0][:, 2 * k] = 2 * cs, -2 * sn
+            FI[1][:, 2 * k - 1], FI[1][:, 2 * k] = -2 * k * sn, -2 * k * cs
+            FI[2][:, 2 * k - 1], FI[2][:, 2 * k] = -2 * k * k * cs, 2 * k * k * sn
+        phys = np.zeros((L * g.zDim, g.V, g.D), dtype=XP)
+        for vi, v in enumerate(g.names):
+            Av = A[:, vi].reshape(g.b_zDim, g.K2, g.b_rDim).astype(XP)
+            if g.has_z:
+                x = g.cheb(v)._x
+                Mx = [x["T"] @ x["CA"], x["TD"] @ x["CA"], x["TDD"] @ x["CA"]]
+            for d, name in enumerate(["u", "r", "rr"]):
+                coef = Av[:, :nb, :] @ PH[d]                                  # [zm, blocks]
+                for ld, sname in ([(0, name)] if d > 0 else [(0, "u"), (1, "l"), (2, "ll")]):
+                    if sname not in sl:
+                        continue
+                    f = coef @ FI[ld].T                                       # [zm, lambda]
+                    if g.has_z:
+                        phys[:, vi, sl[sname]] = (Mx[0] @ f).T.reshape(-1)
+                        if sname == "u":
+                            phys[:, vi, sl["z"]] = (Mx[1] @ f).T.reshape(-1)
+                            phys[:, vi, sl["zz"]] = (Mx[2] @ f).T.reshape(-1)
+                    else:
+                        phys[:, vi, sl[sname]] = f.T.reshape(-1)
+        out[ring] = phys
+    return out
+
+
 class _LazyRings:
     """Dense ring operators are built on first use (the C oracle never needs them)."""
 
@@ -469,12 +517,45 @@ def explicit_timestep(t, ts, u, e_n, e_nm1, e_nm2):
 
 
 def helmholtz_matrix(ch, pxi_bar, tau, extended=False):
-    """calc_Helmholtz_semiimplicit_matrix (src/semiimplicit.jl:768-781)."""
+    """calc_Helmholtz_semiimplicit_matrix (src/semiimplicit.jl:768-781), assembled in extended precision (rounded to
+    double unless extended=True).  The literal Float64 assembly is helmholtz_matrix_f64."""
     c = XP(tau) * XP(tau) * XP(pxi_bar)
     dct, dct2 = ch._x["T"], ch._x["TDD"]
     h = c * dct2 - dct
     H = np.vstack([c * dct[0:1, :], c * dct[-1:, :], h[1:-1, :]])
     return H if extended else np.asarray(H, dtype=np.float64)
+
+
+def helmholtz_matrix_f64(ch, pxi_bar, tau):
+    """calc_Helmholtz_semiimplicit_matrix statement by statement in Float64 (src/semiimplicit.jl:768-781):
+        dct  = Chebyshev.dct_matrix(nz);  dct2 = Chebyshev.dct_2nd_derivative(nz, column_length)          (:772-775)
+        h    = (ts_term .* ts_term .* Pxi_bar) .* dct2 .- dct                                               (:776)
+        bc1, bc2 = (ts_term .* ts_term .* Pxi_bar) .* dct[1, :], ... .* dct[nz, :]                          (:777-778)
+        h_a  = [bc1'; bc2'; h[2:nz-1, :]]                                                                   (:779)
+    with the collocation matrices as Float64 arrays (what the Springsteel functions return)."""
+    dct, dct2 = ch.dct_matrix(), ch.dct_2nd_derivative()
+    c = (tau * tau) * pxi_bar
+    h = c * dct2 - dct
+    return np.vstack([(c * dct[0, :])[None, :], (c * dct[-1, :])[None, :], h[1:-1, :]])
+
+
+class HelmholtzLU:
+    """`factorize(h_a)` + `h_a \\ g` as the reference executes them (src/semiimplicit.jl:780, 586-589): Julia's
+    factorize of a dense general matrix is LAPACK getrf (partial pivoting), `\\` on the factorisation is getrs -
+    scipy.linalg.lu_factor / lu_solve call the same two routines.  The solution a is the Chebyshev coefficient column
+    of w; CItransform! / CIxtransform (:592, 595) turn it into values and d/dz values."""
+
+    def __init__(self, ch, pxi_bar, tau):
+        from scipy.linalg import lu_factor
+        self.ch = ch
+        self.H = helmholtz_matrix_f64(ch, pxi_bar, tau)
+        self.lu = lu_factor(self.H)
+
+    def solve(self, rhs_cols):
+        """rhs_cols [ncol, nz] -> (w values [ncol, nz], dw/dz values [ncol, nz])."""
+        from scipy.linalg import lu_solve
+        a = lu_solve(self.lu, np.ascontiguousarray(rhs_cols.T))          # [nz, ncol]
+        return (self.ch.T @ a).T, (self.ch.T @ (self.ch.Dc @ a)).T
 
 
 def inverse_extended(H):
@@ -682,10 +763,15 @@ class Model:
     """One patch split into radial tiles, stepped with the reference's per-step protocol
     (src/semiimplicit.jl:258-332). Pure numpy; small cases only."""
 
-    def __init__(self, grid, equation_set, ts, params, tiles=None, semiimplicit=False, pxi_bar=0.0):
+    def __init__(self, grid, equation_set, ts, params, tiles=None, semiimplicit=False, pxi_bar=0.0, helmholtz="extended"):
+        """helmholtz = "extended": the Helmholtz operator inverted once in extended precision ("truth" arbiter: what the
+        column solve would return in exact arithmetic, to ~1e-15);  "lu": the reference's own arithmetic, a Float64
+        matrix factorised by LAPACK getrf and solved per column by getrs (HelmholtzLU)."""
         self.g, self.eq, self.ts, self.par = grid, equation_set, float(ts), dict(params)
         self.tiles = tiles or [(0, grid.nc)]
         self.semi, self.pxi = semiimplicit, pxi_bar
+        self.helmholtz = helmholtz
+        self._lu = {}
         self.hist = [dict(e1=None, e2=None, i1=None, i2=None) for _ in self.tiles]
         self.A = None
         self.t = 0
@@ -761,7 +847,13 @@ class Model:
         gg = xi_star_z - star[wi]
         rhs = np.zeros_like(gg)
         rhs[:, 2:] = gg[:, 1:nz - 1]
-        W, X = semi_matrices(chw, self.pxi, tau)
-        out[:, wi] = (rhs @ W.T).reshape(-1)
-        out[:, xi] = (xi_star - tau * (rhs @ X.T)).reshape(-1)
+        if self.helmholtz == "lu":
+            if tau not in self._lu:
+                self._lu[tau] = HelmholtzLU(chw, self.pxi, tau)
+            w_val, w_z = self._lu[tau].solve(rhs)
+        else:
+            W, X = semi_matrices(chw, self.pxi, tau)
+            w_val, w_z = rhs @ W.T, rhs @ X.T
+        out[:, wi] = w_val.reshape(-1)
+        out[:, xi] = (xi_star - tau * w_z).reshape(-1)
         return out

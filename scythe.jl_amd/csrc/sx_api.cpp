@@ -259,6 +259,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->uniform_L = h->has_l ? g->ring_uniform_L : 0;
     h->f32 = g->storage_f32 ? 1 : 0;
     h->overlap = getenv("SX_OVERLAP") && atoi(getenv("SX_OVERLAP")) != 0;
+    h->wide = !(getenv("SX_WIDE") && atoi(getenv("SX_WIDE")) == 0);
     h->cell0 = g->tile_cell0; h->ncells = g->tile_num_cells; h->tile_num = g->tile_num;
     h->nrings = MUBAR * h->ncells; h->nbt = h->ncells + 3;
     for (int i = 0; i < 7; i++) h->slot[i] = DERIV_SLOTS[h->geom][i];
@@ -851,14 +852,12 @@ int sx_check_nan(sx_handle *h, int32_t *flag) {
 int sx_max_abs(sx_handle *h, double *out) {
     clear_error();
     if (!h || !out) { set_error("null argument"); return 1; }
-    unsigned long long *d = nullptr;
-    HIPOK(hipMalloc(&d, sizeof(unsigned long long) * h->V));
-    launch_max_abs(h, d);
+    // persistent device scratch (allocated on first use, freed with the handle): no hipMalloc / hipFree per call
+    if (!h->d_maxabs && !dalloc(h, &h->d_maxabs, (size_t)h->V)) return 1;
+    launch_max_abs(h, h->d_maxabs);
     std::vector<unsigned long long> bits(h->V);
-    hipError_t e = hipMemcpyAsync(bits.data(), d, sizeof(unsigned long long) * h->V, hipMemcpyDeviceToHost, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(d);
-    if (e != hipSuccess) { set_error(std::string("sx_max_abs: ") + hipGetErrorString(e)); return 1; }
+    HIPOK(hipMemcpyAsync(bits.data(), h->d_maxabs, sizeof(unsigned long long) * h->V, hipMemcpyDeviceToHost, h->stream));
+    HIPOK(hipStreamSynchronize(h->stream));
     for (int v = 0; v < h->V; v++) std::memcpy(&out[v], &bits[v], sizeof(double));
     return status();
 }

@@ -229,13 +229,30 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                 // last pass goes back to LDS, then the whole workgroup writes full 128-byte lines
                 fft_inplace<LOGL, +1, true>(X, tw, t, active);
                 lds_barrier();       // also orders the previous slot's copy-out reads (other set) before that set is restaged
-                // thread -> (level zz, ring point l0 + (512 / FZC) i): consecutive lanes cover the FZC levels of one point
-                const int zz = threadIdx.x & (FZC - 1);
-                const double *src = reinterpret_cast<const double *>(set + (zz >> 1) * (L + SKEW)) + (zz & 1);
+                // thread -> (level pair zp, ring point l0 + (2 * 512 / FZC) i): a transform's LDS element l IS the pair of levels
+                // (2 zp, 2 zp + 1) of ring point l, so it leaves as one 16-byte store (8 bytes for fp32-stored slots);
+                // consecutive lanes cover the FZC levels of one point = one 128-byte line.  16 B per lane matters: at 8 B
+                // per lane the vector-memory pipe of a CU moves ~7 B/clk, about half of what the kernel needs.
+                const int zp = threadIdx.x & (FNP - 1);
+                const double2 *src2 = set + zp * (L + SKEW);
                 auto copy_out = [&](auto *out) {
-                    if (zz < zc) {
+                    using OT = decltype(+out[0]);
+                    typedef OT ov2 __attribute__((ext_vector_type(2)));
+                    if (pair_ok && 2 * zp + 1 < zc) {
 #pragma unroll 4
-                        for (int l = threadIdx.x >> LOGZ; l < L; l += (int)(blockDim.x >> LOGZ)) __builtin_nontemporal_store((decltype(+out[0]))src[2 * l], out + (int64_t)l * nz + zz);
+                        for (int l = threadIdx.x >> (LOGZ - 1); l < L; l += (int)(blockDim.x >> (LOGZ - 1))) {
+                            const double2 y = src2[l];
+                            ov2 o2;
+                            o2.x = (OT)y.x; o2.y = (OT)y.y;
+                            __builtin_nontemporal_store(o2, reinterpret_cast<ov2 *>(out + (int64_t)l * nz + 2 * zp));
+                        }
+                    } else if (2 * zp < zc) {      // odd zDim (pairs not 16-byte aligned) or the last level of an odd chunk
+                        const bool two = 2 * zp + 1 < zc;
+                        for (int l = threadIdx.x >> (LOGZ - 1); l < L; l += (int)(blockDim.x >> (LOGZ - 1))) {
+                            const double2 y = src2[l];
+                            __builtin_nontemporal_store((OT)y.x, out + (int64_t)l * nz + 2 * zp);
+                            if (two) __builtin_nontemporal_store((OT)y.y, out + (int64_t)l * nz + 2 * zp + 1);
+                        }
                     }
                 };
                 if (slot == 0) copy_out(phys.val + (int64_t)v * N + p0 * nz + z0);
@@ -278,11 +295,28 @@ k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     tw.template init<-1>(twg, t);
     const int64_t p0 = pstart[ring];
     const double *x = np1 + (int64_t)v * N + p0 * nz + z0;
-    double *ba = (double *)smf;
-    for (int o = tid; o < L * FZC; o += blockDim.x) {
-        const int zz = o & (FZC - 1), l = o >> LOGZ;
-        const double val = (zz < zc) ? __builtin_nontemporal_load(x + (int64_t)l * nz + zz) : 0.0;
-        ba[2 * ((zz >> 1) * (L + SKEW) + l) + (zz & 1)] = val;
+    // stage the [ring point][FZC levels] tile: the (2 zp, 2 zp + 1) level pair of a point is one 16-byte load and one
+    // LDS element of transform zp
+    if ((nz & 1) == 0) {
+        typedef double dv2 __attribute__((ext_vector_type(2)));
+        for (int o = tid; o < L * FNP; o += blockDim.x) {
+            const int zp = o & (FNP - 1), l = o >> (LOGZ - 1);
+            double2 val = make_double2(0.0, 0.0);
+            if (2 * zp + 1 < zc) {
+                const dv2 t2 = __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)l * nz + 2 * zp));
+                val = make_double2(t2.x, t2.y);
+            } else if (2 * zp < zc) {
+                val.x = __builtin_nontemporal_load(x + (int64_t)l * nz + 2 * zp);
+            }
+            smf[zp * (L + SKEW) + l] = val;
+        }
+    } else {
+        double *ba = (double *)smf;
+        for (int o = tid; o < L * FZC; o += blockDim.x) {
+            const int zz = o & (FZC - 1), l = o >> LOGZ;
+            const double val = (zz < zc) ? __builtin_nontemporal_load(x + (int64_t)l * nz + zz) : 0.0;
+            ba[2 * ((zz >> 1) * (L + SKEW) + l) + (zz & 1)] = val;
+        }
     }
     __syncthreads();
     double2 *X = smf + (f < FNP ? f : 0) * (L + SKEW);

@@ -111,6 +111,7 @@ struct sx_handle {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 0;
+    int wide = 1;    // 16-byte-per-lane loads / stores in the equation-set kernels (SX_WIDE=0: the 8-byte forms, A/B timing)
     std::vector<int> hmask_full, hmask_eq;       // host copies of d_mask_full / d_mask_eq
     bool in_advance = false;    // set while sx_advance launches the equation set (the diagnostic w plane is then not stored)
     bool L_all_mult4 = false;   // every ring length is a multiple of 4 (native rings are): the MFMA DFT kernels apply
@@ -130,6 +131,7 @@ struct sx_handle {
     double *d_gl = nullptr, *d_gr = nullptr, *d_Lband = nullptr, *d_Larrow = nullptr, *d_Ldinv = nullptr;
     double *d_r = nullptr, *d_cosl = nullptr, *d_sinl = nullptr, *d_z = nullptr;
     int *d_flag = nullptr;
+    unsigned long long *d_maxabs = nullptr;   // [V] scratch of sx_max_abs
     int *d_mask_full = nullptr, *d_mask_eq = nullptr;   // per-variable bit masks of derivative slots to produce
     int mask_eq_bits = 0, mask_full_bits = 0;            // total number of (variable, slot) planes in each mask
     int mask_eq_val = 0, mask_full_val = 0, mask_node_val = 0;   // of which value-slot planes (always fp64)

@@ -671,20 +671,21 @@ __global__ void k_nan_check(const double *__restrict__ x, int64_t n, int *flag) 
     if (bad) atomicOr(flag, 1);
 }
 
-// max |x[v][p]| per variable: the bit pattern of a non-negative double orders like an unsigned integer
+// max |x[v][p]| per variable: the bit pattern of a non-negative double orders like an unsigned integer, and every NaN
+// pattern (sign cleared) orders above +Inf - so a NaN anywhere in the field comes out as NaN, as Julia's maximum(abs, x) does
 __global__ void k_max_abs(const double *__restrict__ x, int64_t N, unsigned long long *__restrict__ out) {
     const int v = blockIdx.y;
     const double *xv = x + (int64_t)v * N;
-    double m = 0.0;
+    unsigned long long m = 0ull;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
-        const double a = fabs(xv[i]);
+        const unsigned long long a = (unsigned long long)__double_as_longlong(xv[i]) & 0x7fffffffffffffffull;
         if (a > m) m = a;
     }
     for (int o = 32; o > 0; o >>= 1) {
-        const double t = __shfl_xor(m, o);
+        const unsigned long long t = __shfl_xor(m, o);
         if (t > m) m = t;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(out + v, (unsigned long long)__double_as_longlong(m));
+    if ((threadIdx.x & 63) == 0) atomicMax(out + v, m);
 }
 
 // ------------------------------------------------------------------------------------------------ equation sets
@@ -1092,13 +1093,51 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
     for (int v = 6; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
 }
 
+// 16 bytes per lane for streams that are 8 bytes per point.  The vector-memory pipe of a CU moves 8-byte-per-lane accesses
+// at about half the rate of 16-byte ones (MI355X_MICROARCH.md: "8-B accesses 0.54-0.70x the 16-B rate", "16 x dwordx2 per
+// lane ... store-ISSUE-bound"), and the equation-set kernels issue ~120 of them per thread.  A wave owns 64 consecutive
+// doubles of every stream; lanes 0-31 fetch TWO consecutive elements of stream a, lanes 32-63 of stream b, and one
+// v_permlane32_swap per dword leaves (a[e], b[e]) in every lane with e = 2 (lane & 31) + (lane >> 5) - which is therefore
+// the element (level) a lane works on.  Stores run the same exchange backwards.  pa / pb already point at the lane's pair.
+typedef double dbl2v __attribute__((ext_vector_type(2)));
+typedef float flt2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int wide_elem(int lane) { return 2 * (lane & 31) + (lane >> 5); }
+
+template <bool NT>
+__device__ __forceinline__ void load_pair(const double *pa, const double *pb, int lane, double &xa, double &xb) {
+    const dbl2v *p = reinterpret_cast<const dbl2v *>(lane < 32 ? pa : pb);
+    const dbl2v t = NT ? __builtin_nontemporal_load(p) : *p;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(__double2loint(t.x), __double2loint(t.y), false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(__double2hiint(t.x), __double2hiint(t.y), false, false);
+    xa = __hiloint2double(r1[0], r0[0]);
+    xb = __hiloint2double(r1[1], r0[1]);
+}
+template <bool NT>
+__device__ __forceinline__ void load_pair(const float *pa, const float *pb, int lane, double &xa, double &xb) {
+    const flt2v *p = reinterpret_cast<const flt2v *>(lane < 32 ? pa : pb);
+    const flt2v t = NT ? __builtin_nontemporal_load(p) : *p;
+    const auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t.x), __float_as_uint(t.y), false, false);
+    xa = (double)__uint_as_float(r0[0]);
+    xb = (double)__uint_as_float(r0[1]);
+}
+// every lane hands over its element of streams a and b; lanes 0-31 then store two consecutive elements of a, lanes 32-63 of b
+__device__ __forceinline__ void store_pair_nt(double *pa, double *pb, int lane, double xa, double xb) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(__double2loint(xa), __double2loint(xb), false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(__double2hiint(xa), __double2hiint(xb), false, false);
+    dbl2v t;
+    t.x = __hiloint2double(r1[0], r0[0]);
+    t.y = __hiloint2double(r1[1], r0[1]);
+    __builtin_nontemporal_store(t, reinterpret_cast<dbl2v *>(lane < 32 ? pa : pb));
+}
+
 // Cell-wise node-space variant ("radial last", uniform rings): one workgroup = LAM azimuths x NZ levels of ONE radial
 // cell, i.e. the 3 rings that share the same 4 spline nodes.  Each thread loads the 14 node transforms of its
 // (lambda, z) at the 4 nodes once (56 values, kept in registers) and evaluates all 3 rings from them, so a node value
 // enters the CU once instead of three times (the ring-wise grouping was bound by L1 fill rate, not by HBM).
 // The column operators of the 3 x LAM columns run as one f64-MFMA batch; the fields are re-formed from the registers
 // after it, ring by ring, for the tendencies.
-template <int NZ, int LAM, class ST>
+// WIDE: 16-byte-per-lane loads / stores with the lane <-> level map of load_pair (needs 64 | LAM * NZ, always true here).
+template <int NZ, int LAM, class ST, bool WIDE>
 __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a, int cell0) {
     constexpr int CS = NZ + 2;
     constexpr int NCOL = 3 * LAM, NT = (NCOL + 15) / 16;
@@ -1108,10 +1147,14 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     __shared__ double Ysep[ALIAS ? 1 : 3][ALIAS ? 1 : NT * 16 * CS];
     double (*Y)[NT * 16 * CS] = ALIAS ? X : reinterpret_cast<double (*)[NT * 16 * CS]>(&Ysep[0][0]);
     __shared__ double s1[2][NCOL];
-    const int k = threadIdx.x % NZ, ll = threadIdx.x / NZ;
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+    const int elem = WIDE ? wbase + wide_elem(lane) : (int)threadIdx.x;      // element of the workgroup's LAM x NZ block
+    const int k = elem % NZ, ll = elem / NZ;
     const int nlb = a.L / LAM;
     const int cell = cell0 + blockIdx.x / nlb;
     const int lam = (blockIdx.x % nlb) * LAM + ll;
+    // offset of this lane's PAIR inside a stream of the workgroup's block (WIDE)
+    const int64_t pairo = (int64_t)(blockIdx.x % nlb) * LAM * NZ + wbase + 2 * (lane & 31);
     const double *par = a.par;
     const double g = par[SX_P_G], Kh = par[SX_P_KH], Hfree = par[SX_P_HFREE], f = par[SX_P_F];
     const int64_t gp = ((int64_t)cell * a.L + lam) * NZ + k;
@@ -1145,19 +1188,49 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
         const ST *gq = a.G.der + ((int64_t)((s) - 1) * a.V + (v)) * a.NG + gp;                     \
         dst[0] = gq[0]; dst[1] = gq[gs]; dst[2] = gq[2 * gs]; dst[3] = gq[3 * gs];                 \
     }
-    GLOADV(qub, 3) GLOAD(qubz, 3, a.s_z) GLOAD(qvbz, 4, a.s_z) GLOAD(qvbl, 4, a.s_l) GLOADV(qvb, 4)
-    GLOADV(qh, 0) GLOAD(qhl, 0, a.s_l) GLOADV(qug, 1) GLOAD(qugl, 1, a.s_l) GLOADV(qvg, 2) GLOAD(qvgl, 2, a.s_l)
-    GLOAD(qubl, 3, a.s_l) GLOAD(qubll, 3, a.s_ll) GLOAD(qvbll, 4, a.s_ll)
+    const int64_t gw = (int64_t)cell * a.L * NZ + pairo;       // this lane's pair at node 0 of the cell
+#define WLOADV(dst, v)                                                                             \
+    {                                                                                              \
+        const double *gq = a.G.val + (int64_t)(v) * a.NG + gw;                                     \
+        load_pair<false>(gq, gq + gs, lane, dst[0], dst[1]);                                       \
+        load_pair<false>(gq + 2 * gs, gq + 3 * gs, lane, dst[2], dst[3]);                          \
+    }
+#define WLOAD(dst, v, s)                                                                           \
+    {                                                                                              \
+        const ST *gq = a.G.der + ((int64_t)((s) - 1) * a.V + (v)) * a.NG + gw;                     \
+        load_pair<false>(gq, gq + gs, lane, dst[0], dst[1]);                                       \
+        load_pair<false>(gq + 2 * gs, gq + 3 * gs, lane, dst[2], dst[3]);                          \
+    }
+    if (WIDE) {
+        WLOADV(qub, 3) WLOAD(qubz, 3, a.s_z) WLOAD(qvbz, 4, a.s_z) WLOAD(qvbl, 4, a.s_l) WLOADV(qvb, 4)
+        WLOADV(qh, 0) WLOAD(qhl, 0, a.s_l) WLOADV(qug, 1) WLOAD(qugl, 1, a.s_l) WLOADV(qvg, 2) WLOAD(qvgl, 2, a.s_l)
+        WLOAD(qubl, 3, a.s_l) WLOAD(qubll, 3, a.s_ll) WLOAD(qvbll, 4, a.s_ll)
+    } else {
+        GLOADV(qub, 3) GLOAD(qubz, 3, a.s_z) GLOAD(qvbz, 4, a.s_z) GLOAD(qvbl, 4, a.s_l) GLOADV(qvb, 4)
+        GLOADV(qh, 0) GLOAD(qhl, 0, a.s_l) GLOADV(qug, 1) GLOAD(qugl, 1, a.s_l) GLOADV(qvg, 2) GLOAD(qvgl, 2, a.s_l)
+        GLOAD(qubl, 3, a.s_l) GLOAD(qubll, 3, a.s_ll) GLOAD(qvbll, 4, a.s_ll)
+    }
+#undef WLOAD
+#undef WLOADV
 #undef GLOAD
 #undef GLOADV
     // tendency history of ring mu = 0, fetched now (latency hidden behind the operator phase); the next ring's is
     // fetched while the current ring is finished
     double e1h[MUBAR][5], e2h[MUBAR][5];
     const int64_t pc = ((int64_t)(cell * MUBAR) * a.L + lam) * NZ + k;      // ring mu = 0; + mu * L * NZ for the others
+    const int64_t pw = (int64_t)(cell * MUBAR) * a.L * NZ + pairo;            // this lane's pair on ring mu = 0
+    // WIDE: expdot_nm1 / nm2 of a variable travel as one pair; before step 3 the buffers exist but hold no history yet
 #define HIST(mu)                                                                                   \
     _Pragma("unroll") for (int v = 0; v < 5; v++) {                                                \
-        e1h[mu][v] = (a.t >= 2) ? __builtin_nontemporal_load(a.E1 + (int64_t)v * a.N + pc + (mu) * gs) : 0.0;   \
-        e2h[mu][v] = (a.t >= 3) ? __builtin_nontemporal_load(a.E2 + (int64_t)v * a.N + pc + (mu) * gs) : 0.0;   \
+        if (WIDE) {                                                                                \
+            if (a.t >= 2) {                                                                        \
+                load_pair<true>(a.E1 + (int64_t)v * a.N + pw + (mu) * gs, a.E2 + (int64_t)v * a.N + pw + (mu) * gs, lane, e1h[mu][v], e2h[mu][v]);   \
+                if (a.t < 3) e2h[mu][v] = 0.0;                                                     \
+            } else { e1h[mu][v] = 0.0; e2h[mu][v] = 0.0; }                                         \
+        } else {                                                                                   \
+            e1h[mu][v] = (a.t >= 2) ? __builtin_nontemporal_load(a.E1 + (int64_t)v * a.N + pc + (mu) * gs) : 0.0;   \
+            e2h[mu][v] = (a.t >= 3) ? __builtin_nontemporal_load(a.E2 + (int64_t)v * a.N + pc + (mu) * gs) : 0.0;   \
+        }                                                                                          \
     }
     HIST(0)
 #define DOT(w, q) ((w)[0] * q[0] + (w)[1] * q[1] + (w)[2] * q[2] + (w)[3] * q[3])
@@ -1239,6 +1312,7 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
         }
     }
     __syncthreads();
+    double wb_keep = 0.0;
 #pragma unroll
     for (int mu = 0; mu < MUBAR; mu++) {
         const int64_t p = pc + mu * gs;
@@ -1266,15 +1340,27 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
 #pragma unroll
         for (int v = 0; v < 5; v++) {          // explicit_timestep (src/semiimplicit.jl:672-698)
             const int64_t o = (int64_t)v * a.N + p;
-            __builtin_nontemporal_store(ee[v], a.En + o);      // read again only by the next step
             double un;
             if (a.t == 1) un = uu[v] + (a.ts * ee[v]);
             else if (a.t == 2) un = uu[v] + (0.5 * a.ts) * ((3.0 * ee[v]) - e1h[mu][v]);
             else un = uu[v] + ((a.ts / 12.0) * ((23.0 * ee[v]) - (16.0 * e1h[mu][v]) + (5.0 * e2h[mu][v])));
-            __builtin_nontemporal_store(un, a.np1 + o);      // 0.4 GB per step: next read by the forward transform, after
-                                                             // everything else of this kernel has gone through the caches
+            // expdot_n is read again only by the next step; var_np1 (0.4 GB per step) next by the forward transform, after
+            // everything else of this kernel has gone through the caches: both non-temporal
+            if (WIDE) {
+                const int64_t ow = (int64_t)v * a.N + pw + mu * gs;
+                store_pair_nt(a.En + ow, a.np1 + ow, lane, ee[v], un);
+            } else {
+                __builtin_nontemporal_store(ee[v], a.En + o);
+                __builtin_nontemporal_store(un, a.np1 + o);
+            }
         }
-        __builtin_nontemporal_store(wb, a.np1 + (int64_t)5 * a.N + p);
+        if (WIDE) {        // the diagnostic w of rings 0 and 1 leaves as one pair, ring 2's on its own
+            if (mu == 0) wb_keep = wb;
+            else if (mu == 1) store_pair_nt(a.np1 + (int64_t)5 * a.N + pw, a.np1 + (int64_t)5 * a.N + pw + gs, lane, wb_keep, wb);
+            else __builtin_nontemporal_store(wb, a.np1 + (int64_t)5 * a.N + p);
+        } else {
+            __builtin_nontemporal_store(wb, a.np1 + (int64_t)5 * a.N + p);
+        }
     }
 #undef DOT
 #undef HIST
@@ -1441,16 +1527,15 @@ static void launch_physics_t(sx_handle *h, int t, int part) {
             timer_begin(h, id);
             a.col0 = split; a.col1 = h->Nh;
             const int ncell = (h->nrings - h->R_in) / MUBAR;         // R_in is a multiple of 3 (sx_create)
-            if (h->nz == 64) {
-                constexpr int LAM = 4;      // 2: 0.55 ms (6 of 16 MFMA columns, 1 KB chunks); 4: 0.41 ms
-                hipLaunchKernelGGL((k_phys_hrbl_cell<64, LAM, ST>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 64), 0, h->stream, a, h->R_in / MUBAR);
-            } else if (h->nz == 32) {
-                constexpr int LAM = 8;
-                hipLaunchKernelGGL((k_phys_hrbl_cell<32, LAM, ST>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 32), 0, h->stream, a, h->R_in / MUBAR);
-            } else {
-                constexpr int LAM = 2;
-                hipLaunchKernelGGL((k_phys_hrbl_cell<128, LAM, ST>), dim3(ncell * (h->uniform_L / LAM)), dim3(LAM * 128), 0, h->stream, a, h->R_in / MUBAR);
-            }
+#define CELL_LAUNCH(NZ_, LAM_)                                                                                                     \
+            do {                                                                                                                      \
+                if (h->wide) hipLaunchKernelGGL((k_phys_hrbl_cell<NZ_, LAM_, ST, true>), dim3(ncell * (h->uniform_L / LAM_)), dim3(LAM_ * NZ_), 0, h->stream, a, h->R_in / MUBAR);   \
+                else hipLaunchKernelGGL((k_phys_hrbl_cell<NZ_, LAM_, ST, false>), dim3(ncell * (h->uniform_L / LAM_)), dim3(LAM_ * NZ_), 0, h->stream, a, h->R_in / MUBAR);          \
+            } while (0)
+            if (h->nz == 64) CELL_LAUNCH(64, 4);      // LAM 2: 0.55 ms (6 of 16 MFMA columns, 1 KB chunks); 4: 0.41 ms
+            else if (h->nz == 32) CELL_LAUNCH(32, 8);
+            else CELL_LAUNCH(128, 2);
+#undef CELL_LAUNCH
             HIPCHK(hipGetLastError());
             timer_end(h);
         }

@@ -142,11 +142,13 @@ def even_tiles(nc, n):
 class OracleModel:
     """C-oracle model (optionally split into tiles) started from the case's initial condition."""
 
-    def __init__(self, case, tiles=None, numpy_twin=False):
+    def __init__(self, case, tiles=None, numpy_twin=False, helmholtz="extended"):
+        """helmholtz="lu" (numpy twin only): the reference's Float64 LU arithmetic for the semi-implicit column solve."""
         self.g = oracle_grid(case)
-        if numpy_twin:
+        if numpy_twin or helmholtz != "extended":
             self.m = O.Model(self.g, case["eq"], case["ts"], case["par"], tiles=tiles,
-                             semiimplicit=case.get("semiimplicit", False), pxi_bar=case["par"].get("Pxi_bar", 0.0))
+                             semiimplicit=case.get("semiimplicit", False), pxi_bar=case["par"].get("Pxi_bar", 0.0),
+                             helmholtz=helmholtz)
         else:
             self.m = OC.ModelOracle(self.g, case["eq"], case["ts"], case["par"], tiles=tiles,
                                     semiimplicit=case.get("semiimplicit", False))
@@ -283,3 +285,76 @@ def config3_rz(num_cells=171, zDim=128):
     c["par"] = dict(K=1.0e-3, Pxi_bar=1.2e5)
     c["ic"] = ic
     return c
+
+
+# ----------------------------------------------------------------------------- measured accuracy of derivative slots
+def ring_points(g, rings):
+    """Index array of the points (z fastest) of the listed patch rings inside a one-tile physical array."""
+    return np.concatenate([np.arange(g.ringstart[r] * g.zDim, (g.ringstart[r] + g.L[r]) * g.zDim) for r in rings])
+
+
+def slot_errors_vs_extended(g, phys, A, rings):
+    """For each derivative slot: max over variables of  max|phys - truth| / scale  on the sampled rings, where `truth` is
+    the inverse transform of the SAME Float64 coefficients A evaluated in extended precision (oracle_np.inverse_xp) and
+    scale is rel_err_per_var's (slot scale floored by the operator gain times the variable's magnitude).
+    This measures the rounding error of one implementation's tileTransform!; it does not depend on any other one."""
+    truth = O.inverse_xp(g, A, rings)
+    t = np.concatenate([truth[r] for r in rings], axis=0)
+    a = phys[ring_points(g, rings)]
+    t64 = np.asarray(t, dtype=np.float64)
+    vmax = [max(np.abs(t64[:, v, 0]).max(), 1e-300) for v in range(a.shape[1])]
+    out = np.zeros(a.shape[2])
+    for d in range(a.shape[2]):
+        gain = max(np.abs(t64[:, v, d]).max() / vmax[v] for v in range(a.shape[1]))
+        for v in range(a.shape[1]):
+            sc = max(np.abs(t64[:, v, d]).max(), gain * vmax[v], 1e-300)
+            out[d] = max(out[d], float(np.abs(a[:, v, d].astype(O.XP) - t[:, v, d]).max()) / sc)
+    return out
+
+
+def report_slots(title, g, rows):
+    print("\n%s - max error per derivative slot, relative to the slot's scale" % title)
+    print("  %-44s" % "" + "".join("%10s" % s for s in g.slots))
+    for name, e in rows:
+        print("  %-44s" % name + "".join("%10.1e" % x for x in e))
+
+
+def per_slot_errors(a, b):
+    """rel_err_per_var slot by slot: [D]."""
+    return np.array([rel_err_per_var(a[:, :, k:k + 1], b[:, :, k:k + 1]) for k in range(a.shape[2])])
+
+
+def check_full(hip, orc, rings, title, orc_alt=None):
+    """Parity at full size, in separately measured parts:
+    (1) STATE: the A coefficients and the value slot of HIP and oracle agree to 1e-10 after the steps.
+    (2) TRANSFORM ACCURACY (tests/py::slot_errors_vs_extended): each side's derivative slots against the
+        extended-precision evaluation of ITS OWN coefficients on a sample of rings (innermost, middle, outermost = largest
+        kmax).  Demanded: the HIP path is no less accurate than the fp64 oracle, err(HIP) <= 2 err(oracle) (+ 2e-15 for
+        slots the oracle happens to hit exactly).
+    (3) WHOLE GRID, slot by slot, HIP vs oracle.  The derivative operators amplify the last-bit differences of two fp64
+        states by k, k^2 (azimuth) or N^2, N^4 (Chebyshev), so two CORRECT runs differ in those slots by far more than
+        1e-10 of the slot's scale.  The noise floor is measured, not assumed: `orc_alt` is the same oracle with the patch
+        split into two tiles (another summation order of the same arithmetic); HIP must be within 10 x that floor."""
+    a, b = hip.physical(), orc.physical()
+    assert np.isfinite(a).all()
+    eA = rel_err(hip.A, orc.A)
+    vals = max(np.abs(a[:, v, 0] - b[:, v, 0]).max() / np.abs(b[:, v, 0]).max()
+               for v in range(b.shape[1]) if np.abs(b[:, v, 0]).max() > 0)
+    g = orc.g
+    e_hip = slot_errors_vs_extended(g, a, np.asarray(hip.A), rings)
+    e_orc = slot_errors_vs_extended(g, b, np.asarray(orc.A), rings)
+    d = per_slot_errors(a, b)
+    rows = [("HIP vs extended precision (own A)", e_hip), ("fp64 oracle vs extended precision (own A)", e_orc),
+            ("HIP vs fp64 oracle (whole grid)", d)]
+    floor = None
+    if orc_alt is not None:
+        floor = per_slot_errors(orc_alt.physical(), b)
+        rows.append(("oracle, 2 tiles vs 1 tile (fp64 noise floor)", floor))
+    report_slots(title + " (A coefficients %.1e, values %.1e)" % (eA, vals), g, rows)
+    assert eA < 1e-10 and vals < 1e-10, (eA, vals)
+    assert (e_hip <= 2.0 * e_orc + 2e-15).all(), (e_hip, e_orc)
+    if floor is not None:
+        assert (d <= 10.0 * floor + 1e-12).all(), (d, floor)
+    return e_hip, e_orc, d
+
+

@@ -6,29 +6,24 @@ import pytest
 from tests import cases
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-10        # the model fields (derivative slot 1 = values)
-TOL_DERIV = 1e-6   # derivative slots at full size: with kmax = 300 the lambda-derivatives amplify the 1e-16 rounding
-                   # difference between two correct implementations by k^2 .. k^3 (diagnostic w is itself built from
-                   # lambda-derivatives); the small-size suites in test_gpu_parity.py hold every slot to 1e-10
+TOL = 1e-10        # the model fields (derivative slot 1 = values) and the spectral state (A coefficients)
 
 
-def _check(hip_phys, ref_phys):
-    assert cases.rel_err(hip_phys[:, :, :1], ref_phys[:, :, :1]) < TOL
-    vals = max(np.abs(hip_phys[:, v, 0] - ref_phys[:, v, 0]).max() / np.abs(ref_phys[:, v, 0]).max()
-               for v in range(ref_phys.shape[1]) if np.abs(ref_phys[:, v, 0]).max() > 0)
-    assert vals < TOL, vals
-    assert cases.rel_err_per_var(hip_phys, ref_phys) < TOL_DERIV
+_per_slot, _report, _check = cases.per_slot_errors, cases.report_slots, cases.check_full
 
 
 def test_config2_rl_slab_literal_100_cells():
     case = cases.config2_literal()
     hip = cases.HipModel(case)
     orc = cases.OracleModel(case)
+    alt = cases.OracleModel(case, tiles=[(0, 70), (70, 30)])
     assert hip.run.tiles[0].N == 181800
     for _ in range(3):
         hip.step()
         orc.step()
-    _check(hip.physical(), orc.physical())
+        alt.step()
+    _check(hip, orc, [0, 1, 2, 30, 149, 150, 151, 297, 298, 299], "config 2 (RL 100 cells, native rings, kmax 300), 3 steps",
+           orc_alt=alt)
 
 
 def test_config2_two_tiles_balance_gridpoints():
@@ -37,21 +32,53 @@ def test_config2_two_tiles_balance_gridpoints():
     two = cases.HipModel(case, num_tiles=2)
     n = [g.N for g in two.run.tiles]
     assert sum(n) == 181800 and abs(n[0] - n[1]) / 181800 < 0.02       # calcTileSizes balances points, not cells
+    lay = two.run.layout
+    o1 = cases.OracleModel(case)
+    o2 = cases.OracleModel(case, tiles=list(zip(lay.cell0, lay.ncells)))
     for _ in range(3):
-        one.step()
-        two.step()
-    _check(two.physical(), one.physical())
+        for m in (one, two, o1, o2):
+            m.step()
+    a, b = two.physical(), one.physical()
+    assert cases.rel_err(a[:, :, :1], b[:, :, :1]) < TOL
+    # two tilings of the HIP path differ by no more than the same two tilings of the fp64 oracle do (x 10)
+    d, floor = _per_slot(a, b), _per_slot(o2.physical(), o1.physical())
+    _report("config 2, two tiles vs one tile", o1.g, [("HIP", d), ("fp64 oracle", floor)])
+    assert (d <= 10.0 * floor + 1e-12).all(), (d, floor)
 
 
-def test_config3_rz_513x128_semiimplicit():
+def test_config3_rz_513x128_semiimplicit_three_way():
+    """Config 3 at full size, the semi-implicit column solve three ways:
+      HIP        - the product (Helmholtz operator inverted once in extended precision at sx_create, csrc/sx_setup.cpp)
+      LU oracle  - the reference's own arithmetic: Float64 matrix, LAPACK getrf / getrs per column (src/semiimplicit.jl:768-781, 589)
+      extended   - the oracle's extended-precision inverse: what the column solve returns in exact arithmetic
+    Reported: HIP vs LU, HIP vs extended, LU vs extended, for the fields and for every derivative slot."""
     case = cases.config3_rz()
     hip = cases.HipModel(case)
-    orc = cases.OracleModel(case)
+    ext = cases.OracleModel(case)
+    lu = cases.OracleModel(case, helmholtz="lu")
     assert hip.run.tiles[0].N == 513 * 128
     for _ in range(6):
         hip.step()
-        orc.step()
-    _check(hip.physical(), orc.physical())
+        ext.step()
+        lu.step()
+    rings = list(range(0, 513, 19))
+    alt = cases.OracleModel(case, tiles=[(0, 100), (100, 71)])
+    for _ in range(6):
+        alt.step()
+    _check(hip, ext, rings, "config 3 (RZ 513 x 128, semi-implicit), 6 steps, HIP vs extended-precision Helmholtz oracle", orc_alt=alt)
+    ph, pe, pl = hip.physical(), ext.physical(), lu.physical()
+    val = lambda x, y: max(np.abs(x[:, v, 0] - y[:, v, 0]).max() / np.abs(y[:, v, 0]).max() for v in range(y.shape[1]))
+    three = {"HIP vs LU oracle": (val(ph, pl), cases.rel_err_per_var(ph, pl)),
+             "HIP vs extended": (val(ph, pe), cases.rel_err_per_var(ph, pe)),
+             "LU oracle vs extended": (val(pl, pe), cases.rel_err_per_var(pl, pe))}
+    print("\nconfig 3 three-way (fields, all derivative slots):")
+    for k, (a, b) in three.items():
+        print("  %-24s %.2e  %.2e" % (k, a, b))
+    # the model fields agree to 1e-10 in all three pairs: the 1e-10 claim holds against the reference's LU arithmetic too
+    for k, (a, _) in three.items():
+        assert a < TOL, (k, a)
+    # derivative slots: the HIP path is as close to the reference's arithmetic as the exact solve is (N^4-amplified rounding)
+    assert three["HIP vs LU oracle"][1] <= 2.0 * three["LU oracle vs extended"][1] + 1e-12
 
 
 def _bench_model(num_tiles, exchange="a2a", split="reference"):

@@ -166,3 +166,13 @@ def test_cost_balanced_tile_split_for_uniform_rings():
     assert S.PatchLayout(native, 3, split="cost").ncells == S.PatchLayout(native, 3).ncells
     with pytest.raises(ValueError):
         S.PatchLayout(gp, 2, split="nope")
+
+
+def test_output_time_tag_is_julias_string_of_round_t_2():
+    """write_output names its files string(round(t; digits=2)) (src/io.jl:5): 3 * 0.1 -> "0.3", not 0.30000000000000004."""
+    from scythe_jl_amd.io import julia_float_string as j, output_time_tag as tag
+    for x, want in {0.0: "0.0", 100.0: "100.0", 0.3: "0.3", 1e6: "1.0e6", 1234567.0: "1.234567e6", 123456.0: "123456.0",
+                    1e-5: "1.0e-5", 0.0001: "0.0001", 10800.0: "10800.0", 2.5e-7: "2.5e-7", -3.25: "-3.25", 1e22: "1.0e22"}.items():
+        assert j(x) == want, (x, j(x), want)
+    assert tag(3 * 0.1) == "0.3" and tag(100.0) == "100.0" and tag(0.0) == "0.0" and tag(86400.004) == "86400.0"
+    assert tag(2000 * 0.05) == "100.0"          # the notebook's final file: physical_out_100.0.csv

@@ -133,3 +133,81 @@ def test_helmholtz_solution_satisfies_dirichlet_rows():
     g[2:] = np.random.default_rng(7).standard_normal(14)
     w = ch.T @ np.linalg.solve(H, g)
     assert abs(w[0]) < 1e-9 * np.abs(w).max() and abs(w[-1]) < 1e-9 * np.abs(w).max()
+
+
+# ----------------------------------------------------------------------------- pins to the named third-party algorithms
+# Springsteel's ring / column transforms are FFTW plans (R2HC / HC2R for the Fourier rings, REDFT00 for the Chebyshev
+# columns).  numpy.fft.rfft / irfft and scipy.fft.dct(type=1) implement the same published definitions
+# (unnormalised sums), so the oracle's dense operators are pinned to them here: normalisation placement, sign of the
+# imaginary part, phase reference and bottom-first ordering included.
+@pytest.mark.parametrize("L,kmax,off", [(8, 1, 0.0), (20, 4, 0.37), (256, 127, 0.0), (364, 90, 0.5 * (2 * np.pi / 364) * 89), (31, 15, 1.3)])
+def test_ring_operators_are_fftw_r2hc_hc2r(L, kmax, off):
+    rg = O.Ring(L, kmax, off)
+    rng = np.random.default_rng(L)
+    u = rng.standard_normal(L)
+    k = np.arange(kmax + 1)
+    # forward: FB = (R2HC / L) rotated to the common lambda = 0 reference:  b_k = e^{-i k off} rfft(u)[k] / L
+    spec = np.exp(-1j * k * off) * np.fft.rfft(u)[: kmax + 1] / L
+    c = rg.FB @ u
+    assert abs(c[0] - spec[0].real) < 1e-15 * L
+    assert np.max(np.abs(c[1::2] - spec[1:].real)) < 1e-14 and np.max(np.abs(c[2::2] - spec[1:].imag)) < 1e-14
+    # inverse: FI = HC2R of the rotated-back half-complex spectrum, truncated at kmax:  u = L irfft(e^{+i k off} a)
+    a = rng.standard_normal(1 + 2 * kmax)
+    full = np.zeros(L // 2 + 1, dtype=complex)
+    full[0] = a[0]
+    full[1: kmax + 1] = (a[1::2] + 1j * a[2::2]) * np.exp(1j * k[1:] * off)
+    if L % 2 == 0 and kmax == L // 2:
+        pytest.skip("Nyquist bin is never kept (kmax < L / 2)")
+    for ld, fac in ((0, np.ones(L // 2 + 1)), (1, 1j * np.arange(L // 2 + 1)), (2, -np.arange(L // 2 + 1) ** 2.0)):
+        ref = L * np.fft.irfft(fac * full, n=L)
+        scale = max(np.abs(ref).max(), 1.0)
+        assert np.max(np.abs(rg.FI[ld] @ a - ref)) < 1e-13 * scale
+
+
+@pytest.mark.parametrize("N,bdim", [(9, 9), (16, 11), (64, 43), (128, 128)])
+def test_chebyshev_operators_are_fftw_redft00(N, bdim):
+    from scipy.fft import dct
+    ch = O.Cheb(0.0, 7.0, N, bdim)
+    rng = np.random.default_rng(N)
+    u = rng.standard_normal(N)                                     # index 0 = bottom (z = zmin)
+    # CB = REDFT00 / (2 (N - 1)), first b_zDim coefficients
+    assert np.max(np.abs(ch.CBm @ u - dct(u, type=1)[:bdim] / (2 * (N - 1)))) < 1e-14
+    # CI = REDFT00 of the coefficient column (dct_matrix)
+    a = rng.standard_normal(N)
+    assert np.max(np.abs(ch.T @ a - dct(a, type=1))) < 1e-12
+    # round trip with nothing truncated: REDFT00(REDFT00(u)) = 2 (N - 1) u
+    if bdim == N:
+        assert np.max(np.abs(ch.T @ (ch.CBm @ u) - u)) < 1e-13
+    # bottom-first: a field that grows with height has a NEGATIVE first Chebyshev coefficient (x = +1 is the bottom)
+    assert (ch.CBm @ ch.z)[1] < 0.0
+
+
+# ----------------------------------------------------------------------------- semi-implicit solve: the reference's arithmetic
+@pytest.mark.parametrize("zDim", [16, 64])
+def test_helmholtz_lu_path_is_the_reference_arithmetic_and_agrees_with_the_extended_one(zDim):
+    """HelmholtzLU follows src/semiimplicit.jl:768-781, 586-595 literally (Float64 h_a, getrf, getrs, CItransform!,
+    CIxtransform); the extended-precision inverse is the exact-arithmetic arbiter.  After 5 steps of the RZ model the
+    fields of the two agree to 1e-12: the LU's rounding noise does not reach the model state."""
+    from scipy.linalg import lu_factor, lu_solve
+    ch = O.Cheb(0.0, 1.0e3, zDim, zDim, "R1T0", "R1T0")
+    tau, pxi = 2.5, 1.2e5
+    H = O.helmholtz_matrix_f64(ch, pxi, tau)
+    c = tau * tau * pxi
+    assert np.array_equal(H[0], c * ch.dct_matrix()[0]) and np.array_equal(H[1], c * ch.dct_matrix()[-1])
+    assert np.array_equal(H[2:], (c * ch.dct_2nd_derivative() - ch.dct_matrix())[1:-1])
+    g = np.zeros((3, zDim))
+    g[:, 2:] = np.random.default_rng(1).standard_normal((3, zDim - 2))
+    w, wz = O.HelmholtzLU(ch, pxi, tau).solve(g)
+    a = lu_solve(lu_factor(H), g.T)
+    assert np.array_equal(w, (ch.T @ a).T)
+    W, X = O.semi_matrices(ch, pxi, tau)
+    assert np.max(np.abs(w - g @ W.T)) < 1e-11 * np.abs(w).max()
+    case = cases.config3_rz(num_cells=6, zDim=zDim)
+    m_ext = cases.OracleModel(case, numpy_twin=True)
+    m_lu = cases.OracleModel(case, helmholtz="lu")
+    for _ in range(5):
+        m_ext.step()
+        m_lu.step()
+    pe, pl = m_ext.physical(), m_lu.physical()
+    for v in range(pe.shape[1]):
+        assert np.abs(pe[:, v, 0] - pl[:, v, 0]).max() < 1e-12 * np.abs(pe[:, v, 0]).max()
