@@ -38,7 +38,12 @@ def test_notebook_known_answer_through_integrate_model(tmp_path, num_tiles):
     # notebook cells 7 and 9
     read = lambda t: np.loadtxt(os.path.join(model.output_dir, "physical_out_%s.csv" % t), delimiter=",", skiprows=1)
     initial, mid, final = read(0.0), read(50.0), read(100.0)
-    assert initial.shape == (300, 2) and mid.shape == (300, 2)
+    assert initial.shape == (300, 4) and mid.shape == (300, 4)          # r, u, u_r, u_rr
+    with open(os.path.join(model.output_dir, "physical_out_100.0.csv")) as f:
+        assert f.readline().strip() == "r,u,u_r,u_rr"
+    if num_tiles == 1:
+        spec = np.loadtxt(os.path.join(model.output_dir, "spectral_out_100.0.csv"), delimiter=",", skiprows=1)
+        assert spec.shape == (103, 2)                                  # b_rDim = num_cells + 3 spline coefficients
     rel = np.max(np.abs(final[IDX, 1] / np.array(KAT["final_u"]) - 1.0))
     assert rel < 1e-11, rel
     l2 = np.sqrt(np.sum((initial[:, 1] - final[:, 1]) ** 2))
