@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_ACHIEVABLE_GBS = 6300.0   # same guide: 6.29 TB/s measured for a float4 copy (79 % of spec)
+PROFILE_ROUND = "r02"     # profiles/<round>/pmc_traffic_<workload>.json: the PMC passes of the current build
 
 WORKLOADS = {
     # name: (num_cells, ring_L, zDim)
@@ -67,33 +69,46 @@ def grid_kwargs(workload):
 
 
 def cpu_baseline(workload, sample_cells, steps):
-    """Time the C oracle (oracle/scythe_oracle.c, OpenMP) on a radial sample of the workload: `sample_cells` cells
-    from the middle of the patch with the full azimuthal x vertical extent, plus the full-patch B->A solve."""
+    """Time the C oracle (oracle/scythe_oracle.c, OpenMP; a restatement, NOT Julia) on the workload.
+    sample_cells = 0: the FULL grid (every radial cell), `steps` timed steps after one warm-up step - a measurement.
+    sample_cells > 0: that many cells from the middle of the patch with the full azimuthal x vertical extent, plus the
+    full-patch B->A solve, scaled to the grid - an extrapolation, kept for quick runs and reported beside the measurement."""
     from oracle import oracle_np as O, oracle_c as OC
     # the GPU box's CPU share for one GPU is 16 cores; an OMP_NUM_THREADS given by the caller wins
     OC.lib().orc_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1))))
     kw, L = grid_kwargs(workload)
     g = O.Grid(kw.pop("geometry"), kw.pop("xmin"), kw.pop("xmax"), kw.pop("num_cells"), kw.pop("vars"), ring_L=L, **kw)
-    c0 = (g.nc - sample_cells) // 2
-    m = OC.ModelOracle(g, "Oneway_ShallowWater_HeightResolvedBL", TS, PAR, tiles=[(c0, sample_cells)])
-    tl = m.tiles[0]
-    m.A = np.zeros((g.S_patch(), g.V), order="F")
-    shared = np.zeros((g.S_patch(), g.V), order="F")
-    tl.add_to_shared(tl.forward(initial_condition(tl.pts)), shared)
-    m.A = tl.spline_solve(shared)
-    m.step()                                    # warm-up (page faults, thread pool)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        m.step()
-    dt = (time.perf_counter() - t0) / steps
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        tl.spline_solve(shared)                 # the full-patch B->A solve is not proportional to the sample
-    dt_solve = (time.perf_counter() - t0) / steps
-    scale = g.nc / sample_cells
-    full = (dt - dt_solve) * scale + dt_solve
-    return {"value": 1.0 / full, "unit": "steps/s", "cores": OC.lib().orc_num_threads(), "kind": "port",
-            "sample": "%d of %d radial cells (%d rings x %d x %d points, %d vars), %d timed steps: %.3f s/step on the "
+
+    def timed(ncell):
+        c0 = (g.nc - ncell) // 2
+        m = OC.ModelOracle(g, "Oneway_ShallowWater_HeightResolvedBL", TS, PAR, tiles=[(c0, ncell)])
+        tl = m.tiles[0]
+        shared = np.zeros((g.S_patch(), g.V), order="F")
+        tl.add_to_shared(tl.forward(initial_condition(tl.pts)), shared)
+        m.A = tl.spline_solve(shared)
+        m.step()                                    # warm-up (page faults, thread pool)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.step()
+        dt = (time.perf_counter() - t0) / steps
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tl.spline_solve(shared)                 # the full-patch B->A solve is not proportional to the sample
+        return dt, (time.perf_counter() - t0) / steps
+
+    cores = OC.lib().orc_num_threads()
+    if sample_cells <= 0 or sample_cells >= g.nc:
+        dt, _ = timed(g.nc)
+        dts, dsolve = timed(18)
+        extrap = (dts - dsolve) * g.nc / 18 + dsolve
+        return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+                "sample": "the full grid (%d cells = %d rings x %d x %d points, %d vars), %d timed steps after 1 warm-up step: %.3f s/step "
+                          "measured (C restatement with OpenMP, not Julia); for comparison an 18-cell sample scaled to the grid "
+                          "predicts %.3f s/step" % (g.nc, 3 * g.nc, L, g.zDim, g.V, steps, dt, extrap)}
+    dt, dt_solve = timed(sample_cells)
+    full = (dt - dt_solve) * g.nc / sample_cells + dt_solve
+    return {"value": 1.0 / full, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "EXTRAPOLATED from %d of %d radial cells (%d rings x %d x %d points, %d vars), %d timed steps: %.3f s/step on the "
                       "sample of which %.3f s is the full-patch solve; full step = (%.3f - %.3f) * %d/%d + %.3f s"
                       % (sample_cells, g.nc, 3 * sample_cells, L, g.zDim, g.V, steps, dt, dt_solve, dt, dt_solve, g.nc,
                          sample_cells, dt_solve)}
@@ -116,8 +131,12 @@ def main():
     ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
                     help="f32: derivative slots of `physical` stored as fp32 (config 5; not the headline metric, whose "
                          "1e-10 parity bar needs fp64 throughout)")
+    ap.add_argument("--exchange-impl", default="lib", choices=["lib", "torch"],
+                    help="N > 1: 'lib' = ncclSend/Recv/AllGather issued inside libscythe_hip.so on the tile's stream (sx_exchange), "
+                         "'torch' = torch.distributed collectives on device tensors (always used with --backend gloo)")
+    ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip the 2-step comparison of the two exchange implementations")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=18)
+    ap.add_argument("--cpu-sample-cells", type=int, default=0, help="0 = time the C port on the full grid (default); n > 0 = extrapolate from n cells")
     ap.add_argument("--cpu-steps", type=int, default=3)
     args = ap.parse_args()
 
@@ -148,12 +167,38 @@ def main():
     gp = S.GridParameters(ring_uniform_L=L, storage=args.storage, **kw)
     mp = S.ModelParameters(ts=TS_OF.get(args.workload, TS), equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
                            physical_params=dict(PAR))
-    run = S.ModelRun(mp, num_tiles=world, rank=rank, device=torch.device("cuda", local_rank), use_dist=world > 1,
-                     exchange=args.exchange, split=args.tile_split)
+    impl = args.exchange_impl if (world > 1 and args.backend == "nccl") else "torch"
+    dev = torch.device("cuda", local_rank)
+    selfcheck = None
+
+    def make_run(which):
+        r = S.ModelRun(mp, num_tiles=world, rank=rank, device=dev, use_dist=world > 1, exchange=args.exchange, split=args.tile_split,
+                       impl=which)
+        r.set_initial_conditions([initial_condition(S.getGridpoints(r.tiles[0]))])
+        return r
+
+    if world > 1 and impl == "lib":
+        try:
+            run = make_run("lib")
+        except Exception as e:          # RCCL could not be bound / initialised inside the library: say so, use torch's
+            print("bench.py: in-library exchange unavailable (%r), using torch.distributed" % (e,), file=sys.stderr)
+            impl = "torch (lib failed: %s)" % (str(e)[:120],)
+            run = make_run("torch")
+        if impl == "lib" and not args.no_selfcheck:
+            # both implementations of the exchange, two steps each from the same initial condition: same fields
+            other = make_run("torch")
+            for _ in range(2):
+                run.step()
+                other.step()
+            a, b = run.tiles[0].var_np1, other.tiles[0].var_np1
+            selfcheck = float(max(np.abs(a[:, v] - b[:, v]).max() / max(np.abs(b[:, v]).max(), 1e-300) for v in range(a.shape[1])))
+            other.close()
+            del other, a, b
+            run.close()
+            run = make_run("lib")
+    else:
+        run = make_run(impl if world > 1 else "torch")
     tile = run.tiles[0]
-    pts = S.getGridpoints(tile)
-    run.set_initial_conditions([initial_condition(pts)])
-    del pts
 
     def barrier():
         torch.cuda.synchronize()
@@ -191,11 +236,16 @@ def main():
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         nc, _, nz = WORKLOADS[args.workload]
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE,
-        # collected and corrected as profiles/summarize_pmc.py documents); null for other workloads / tilings
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_%s.json" % args.workload)
+        # collected and corrected as profiles/summarize_pmc.py documents) - but only if those passes ran with the very
+        # library loaded now (sha256 recorded by summarize_pmc.py): a stale number is worse than none
+        traffic, step_traffic = None, None
+        tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic_%s.json" % args.workload)
         if world == 1 and args.storage == "f64" and os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(name, {}).get("hbm_bytes")
+            import hashlib
+            pmc = json.load(open(tfile))
+            if pmc.get("_meta", {}).get("lib_sha256") == hashlib.sha256(open(S.LIB_PATH, "rb").read()).hexdigest():
+                traffic = pmc.get(name, {}).get("hbm_bytes")
+                step_traffic = sum(pmc[k]["hbm_bytes"] * (timers[k][1] / args.steps) for k in timers if k in pmc)
         out = {
             "metric": ("model steps/sec, RLZ 512x256x64 shallow-water" if args.workload == "rlz_513x256x64"
                        else "model steps/sec, %s shallow-water (not the headline configuration)" % args.workload),
@@ -213,10 +263,16 @@ def main():
             "config": {"workload": "RLZ %dx%dx%d (rings x azimuth x levels), 6 vars, 7 derivative slots, "
                                    "Oneway_ShallowWater_HeightResolvedBL, uniform ring table kmax<=%d, b_zDim %d"
                                    % (3 * nc, L, nz, L // 2 - 1, int(tile.dims.b_zDim)),
-                       "num_cells": nc, "tiles": world, "tile_cells": list(run.layout.ncells), "exchange": run.exchange_kind, "ts": TS_OF.get(args.workload, TS), "nan": bool(nan)},
+                       "num_cells": nc, "tiles": world, "tile_cells": list(run.layout.ncells), "exchange": run.exchange_kind,
+                       "exchange_impl": (impl if world > 1 else "none"), "exchange_selfcheck_max_rel_diff": selfcheck, "ts": TS_OF.get(args.workload, TS), "nan": bool(nan)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
+                         # whole step: PMC bytes of every kernel of a step / step time (null without matching PMC passes)
+                         "step_traffic": step_traffic,
+                         "step_achieved": (step_traffic / (ms_per_step * 1e-3) / 1e9) if step_traffic else None,
+                         "step_frac": (step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic else None},
             "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -224,6 +280,10 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_cells, args.cpu_steps)
             except Exception as e:   # the baseline is a reported side figure; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        if selfcheck is not None and not (selfcheck < 1e-10):
+            out["value"] = None
+            out["error"] = "in-library RCCL exchange and torch.distributed exchange disagree: %g" % selfcheck
+            nan = True
         if nan:
             # a run that blew up is not a throughput measurement: no value, non-zero exit
             out["value"] = None

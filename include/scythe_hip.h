@@ -157,6 +157,16 @@ int sx_set_patch_spectral_b(sx_handle *h, const double *shared);
 int sx_get_patch_spectral_a(sx_handle *h, double *out);
 int sx_set_patch_spectral_a(sx_handle *h, const double *a);
 
+/* calcPatchMap / calcHaloMap (src/semiimplicit.jl:79-86) as 1-based linear indices into ONE variable's column of the
+ * reference layouts (add (v - 1) * s_patch resp. (v - 1) * s_tile for variable v):
+ *   patch_owned[i] <-> tile_owned[i]   sharedSpectral[patchIndexMap] .= tileView            (:323)   n_owned entries
+ *   patch_halo[i]  <-> tile_halo[i]    put!(haloSend, haloSendView) on this tile (:320);  on the NEXT tile
+ *                                      sharedSpectral[haloReceiveIndexMap] .+= buffer (:326-329) with haloReceiveIndexMap =
+ *                                      this tile's patch_halo                                         n_halo entries
+ * The last tile owns all its rows (n_halo = 0).  Any output pointer may be NULL. */
+int sx_index_map_sizes(const sx_handle *h, int64_t *n_owned, int64_t *n_halo);
+int sx_index_maps(const sx_handle *h, int64_t *patch_owned, int64_t *tile_owned, int64_t *patch_halo, int64_t *tile_halo);
+
 /* --- restart state (the reference can only restart from a physical_out CSV, which loses the
  * Adams-Bashforth history; this blob lets a run continue bit-identically) ------------------------------------------- */
 /* The tile's A coefficients (its own radial nodes) and the tendency history expdot_nm1 / expdot_nm2 (and impdot_nm1 / nm2
@@ -222,6 +232,28 @@ int sx_a2a_col_starts(sx_handle *h, int64_t *out /* [n_tiles + 1] */);
 int sx_a2a_pack_b(sx_handle *h, void *dev_send);
 int sx_a2a_solve(sx_handle *h, const void *dev_recv, void *dev_send);
 int sx_a2a_unpack_a(sx_handle *h, const void *dev_recv);
+
+/* --- exchange over RCCL, inside the library --------------------------------------------------------------------------
+ * One process per GPU, one tile per process (src/semiimplicit.jl:179-184).  The reference's per-step exchange - the halo
+ * chain tile -> tile + 1 (src/semiimplicit.jl:203-219, 320-329), the shared sum on the master (:272-282) and the patch solve
+ * on every worker (:285) - runs here as ncclSend / ncclRecv / ncclAllGather on the handle's stream, ordered with the
+ * kernels by that stream alone.  librccl is bound with dlopen on first use (SX_RCCL_LIB overrides the search; a copy the
+ * process has already mapped is reused).  A Julia host needs only ccall:
+ *   rank 0: sx_comm_unique_id(id) -> hand the 128 bytes to every worker (the master's RemoteChannels will do)
+ *   all   : sx_comm_init(h, n_tiles, my_tile, cell0, ncells, mode, id)      (collective; after hipSetDevice / sx_create)
+ *   step  : sx_advance(h, t); sx_exchange(h);                               (replaces :320-329, :272-285)
+ * mode 0 = transposed solve (two all-to-alls of B / A rows, each rank solves its share of the columns for the whole
+ * patch: scales), mode 1 = the reference's protocol (halo rows to the next tile, all-gather of the owned rows, redundant
+ * patch solve).  tile_cell0 / tile_num_cells describe all n tiles (calcTileSizes rows 4 and 3, 0-based cell0).
+ * sx_comm_attach does the same with a communicator the host already owns (ncclComm_t, e.g. from NCCL.jl); it is not
+ * destroyed with the handle.  After sx_exchange the patch A coefficients this tile evaluates are in place for the next
+ * sx_advance / sx_tile_transform. */
+int sx_comm_unique_id(char *out128);
+int sx_comm_init(sx_handle *h, int32_t n_tiles, int32_t my_tile, const int32_t *tile_cell0, const int32_t *tile_num_cells,
+                 int32_t mode, const char *id128);
+int sx_comm_attach(sx_handle *h, int32_t n_tiles, int32_t my_tile, const int32_t *tile_cell0, const int32_t *tile_num_cells,
+                   int32_t mode, void *nccl_comm);
+int sx_exchange(sx_handle *h);
 
 /* --- measurement ---------------------------------------------------------------------------------------------------- */
 /* hipEvent timers around every kernel on the handle's stream (off by default). */

@@ -137,13 +137,15 @@ class Ring:
     def __init__(self, L, kmax, offset):
         self.L, self.kmax, self.offset = int(L), int(kmax), float(offset)
         self.lam = self.offset + 2.0 * np.pi * np.arange(self.L) / self.L
+        # angles in extended precision, rounded once: in Float64 the product k * lambda alone loses k ulp (1e-13 at k = 300)
+        lam_x = XP(self.offset) + 2 * PI_X * np.arange(self.L, dtype=XP) / XP(self.L)
         nb = 1 + 2 * self.kmax
         self.FB = np.zeros((nb, self.L))
         self.FI = [np.zeros((self.L, nb)) for _ in range(3)]
         self.FB[0, :] = 1.0 / self.L
         self.FI[0][:, 0] = 1.0
         for k in range(1, self.kmax + 1):
-            c, s = np.cos(k * self.lam), np.sin(k * self.lam)
+            c, s = np.cos(k * lam_x).astype(np.float64), np.sin(k * lam_x).astype(np.float64)
             self.FB[2 * k - 1] = c / self.L
             self.FB[2 * k] = -s / self.L
             self.FI[0][:, 2 * k - 1] = 2.0 * c

@@ -19,6 +19,9 @@
  * Parity status: R-grid B-spline/AB3 path pinned by the notebook KAT (tests/golden); everything else
  * "parity unpinned" (see oracle/oracle_np.py header).
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE   /* M_PIl */
+#endif
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -111,8 +114,8 @@ static void trig_init(trig_t *t, int L) {
     t->c = (double *)malloc(sizeof(double) * L);
     t->s = (double *)malloc(sizeof(double) * L);
     for (int j = 0; j < L; j++) {
-        t->c[j] = cos(2.0 * M_PI * j / L);
-        t->s[j] = sin(2.0 * M_PI * j / L);
+        t->c[j] = (double)cosl(2.0L * M_PIl * j / L);
+        t->s[j] = (double)sinl(2.0L * M_PIl * j / L);
     }
 }
 static void trig_free(trig_t *t) { free(t->c); free(t->s); }
@@ -132,7 +135,7 @@ static void ring_forward(const trig_t *tg, int L, int kmax, double off, const do
                 /* X0 = (Z_k + conj Z_-k)/2 ; X1 = (Z_k - conj Z_-k)/(2i) */
                 double ar = 0.5 * (wr[k] + wr[nk]), ai = 0.5 * (wi[k] - wi[nk]);
                 double br = 0.5 * (wi[k] + wi[nk]), bi = -0.5 * (wr[k] - wr[nk]);
-                double pr = cos(k * off), pi = -sin(k * off);
+                double pr = (double)cosl((long double)k * (long double)off), pi = -(double)sinl((long double)k * (long double)off);   /* k * off formed in extended precision: the Float64 product alone loses k ulp */
                 double *c0 = c + (long)ln * cs, *c1 = c + (long)(ln + 1) * cs;
                 if (k == 0) {
                     c0[0] = ar * inv;
@@ -158,7 +161,7 @@ static void ring_forward(const trig_t *tg, int L, int kmax, double off, const do
                     sr += xl[l] * tg->c[j];
                     si -= xl[l] * tg->s[j];
                 }
-                double pr = cos(k * off), pi = -sin(k * off);
+                double pr = (double)cosl((long double)k * (long double)off), pi = -(double)sinl((long double)k * (long double)off);   /* k * off formed in extended precision: the Float64 product alone loses k ulp */
                 if (k == 0) cl[0] = sr * inv;
                 else {
                     cl[2 * k - 1] = (sr * pr - si * pi) * inv;
@@ -183,7 +186,7 @@ static void ring_inverse(const trig_t *tg, int L, int kmax, double off, const do
                     if (ld == 1) { double t = cr; cr = -k * ci; ci = k * t; }
                     else if (ld == 2) { cr *= -(double)k * k; ci *= -(double)k * k; }
                     /* undo the phase reference: multiply by e^{+ik off} */
-                    double pr = cos(k * off), pi = sin(k * off);
+                    double pr = (double)cosl((long double)k * (long double)off), pi = (double)sinl((long double)k * (long double)off);
                     double zr = cr * pr - ci * pi, zi = cr * pi + ci * pr;
                     /* Hermitian extension; sequence q goes into real (q=0) or imaginary (q=1) part */
                     int nk = (L - k) % L;
@@ -211,7 +214,7 @@ static void ring_inverse(const trig_t *tg, int L, int kmax, double off, const do
                 double cr = cl[2 * k - 1], ci = cl[2 * k];
                 if (ld == 1) { double t = cr; cr = -k * ci; ci = k * t; }
                 else if (ld == 2) { cr *= -(double)k * k; ci *= -(double)k * k; }
-                double pr = cos(k * off), pi = sin(k * off);
+                double pr = (double)cosl((long double)k * (long double)off), pi = (double)sinl((long double)k * (long double)off);
                 double zr = 2.0 * (cr * pr - ci * pi), zi = 2.0 * (cr * pi + ci * pr);
                 for (int l = 0; l < L; l++) {
                     int j = (int)(((long)l * k) % L);

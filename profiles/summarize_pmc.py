@@ -1,6 +1,8 @@
 """Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE counter_collection CSVs into per-kernel HBM bytes per launch.
 
-Usage: python profiles/summarize_pmc.py <fetch_csv> <write_csv> <out_json>
+Usage: python profiles/summarize_pmc.py <fetch_csv> <write_csv> <out_json> [<libscythe_hip.so the passes ran with>]
+The library's sha256 is stored under "_meta": bench.py reports roofline.traffic only when the library it has loaded is
+that very build (a changed kernel makes the numbers stale).
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md "HBM": counters are in KiB; on gfx950 FETCH_SIZE reports half
 of the bytes of a coalesced streaming read, so reads are doubled (checked here on k_nan_check, a pure read of a known
 byte count: 2 x FETCH_SIZE = 0.955 of the algorithmic bytes); WRITE_SIZE is taken as is."""
@@ -35,6 +37,7 @@ def load(path, name):
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    lib = sys.argv[4] if len(sys.argv) > 4 else None
     f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
     res = {}
     for k in sorted(set(f) | set(w)):
@@ -45,8 +48,13 @@ def main():
         res[k] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes": rd + wr, "launches_sampled": len(f.get(k, []))}
     if "k_phys_hrbl" not in res and "k_phys_hrbl_inner" in res:      # ring-wise build: one HRBL launch over all rings
         res["k_phys_hrbl"] = res.pop("k_phys_hrbl_inner")
+    if lib:
+        import hashlib
+        res["_meta"] = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(), "lib": lib}
     json.dump(res, open(out, "w"), indent=1)
     for k, v in res.items():
+        if k.startswith("_"):
+            continue
         print("%-22s read %8.1f MB  write %8.1f MB" % (k, v["read_bytes"] / 1e6, v["write_bytes"] / 1e6))
 
 

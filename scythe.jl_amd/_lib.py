@@ -57,6 +57,8 @@ SYMBOLS = {
     "sx_get_physical": (C.c_int, [_H, P_D]),
     "sx_get_var_np1": (C.c_int, [_H, P_D]),
     "sx_cheb_column_ops": (C.c_int, [C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P_D, P_D, P_D, P_D, P_D]),
+    "sx_index_map_sizes": (C.c_int, [_H, P_I64, P_I64]),
+    "sx_index_maps": (C.c_int, [_H, P_I64, P_I64, P_I64, P_I64]),
     "sx_state_size": (C.c_int, [_H, P_I64]),
     "sx_get_state": (C.c_int, [_H, P_D]),
     "sx_set_state": (C.c_int, [_H, P_D]),
@@ -81,6 +83,10 @@ SYMBOLS = {
     "sx_a2a_pack_b": (C.c_int, [_H, C.c_void_p]),
     "sx_a2a_solve": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "sx_a2a_unpack_a": (C.c_int, [_H, C.c_void_p]),
+    "sx_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "sx_comm_init": (C.c_int, [_H, C.c_int32, C.c_int32, P_I32, P_I32, C.c_int32, C.c_char_p]),
+    "sx_comm_attach": (C.c_int, [_H, C.c_int32, C.c_int32, P_I32, P_I32, C.c_int32, C.c_void_p]),
+    "sx_exchange": (C.c_int, [_H]),
     "sx_enable_timers": (C.c_int, [_H, C.c_int32]),
     "sx_reset_timers": (C.c_int, [_H]),
     "sx_get_timers": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_char_p), P_D, P_I64, P_I32]),

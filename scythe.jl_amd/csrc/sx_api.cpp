@@ -16,7 +16,7 @@ void set_error(const std::string &msg) {
     if (!g_err_set) g_err = msg;
     g_err_set = true;
 }
-static void clear_error() { g_err_set = false; }
+void clear_error() { g_err_set = false; }
 static int status() { return g_err_set ? 1 : 0; }
 
 #define HIPOK(x)                                                                          \
@@ -341,12 +341,13 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         if (it == tw_of_L.end()) {
             tw_of_L[L] = (int64_t)tw.size();
             twoff[i] = (int64_t)tw.size();
-            for (int j = 0; j < L; j++) tw.push_back(make_double2(std::cos(2.0 * M_PI * j / L), std::sin(2.0 * M_PI * j / L)));
+            // angles formed in extended precision and rounded once (the Float64 product k * off alone loses k ulp: 1e-13 at k = 300)
+            for (int j = 0; j < L; j++) tw.push_back(make_double2((double)cosl(2.0L * M_PIl * j / L), (double)sinl(2.0L * M_PIl * j / L)));
         } else {
             twoff[i] = it->second;
         }
         phoff[i] = (int64_t)ph.size();
-        for (int k = 0; k <= km; k++) ph.push_back(make_double2(std::cos(k * off), std::sin(k * off)));
+        for (int k = 0; k <= km; k++) ph.push_back(make_double2((double)cosl((long double)k * (long double)off), (double)sinl((long double)k * (long double)off)));
     }
     h->kmax_max = h->kDim_t;
     h->L_all_mult4 = true;
@@ -581,6 +582,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
 int sx_destroy(sx_handle *h) {
     if (!h) return 0;
     hipDeviceSynchronize();
+    comm_release(h);
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -794,6 +796,48 @@ int sx_get_patch_spectral_a(sx_handle *h, double *out) {
                     out[(int64_t)v * h->S_patch + ref_index(zm, blk, m, h->K2ref, h->b_rDim)] =
                         tmp[(size_t)m * h->C + ((size_t)v * h->Zb + zm) * h->K2 + dev_blk(blk)];
     return status();
+}
+
+// calcPatchMap / calcHaloMap (src/semiimplicit.jl:79-86): where the entries of one variable's tile.spectral column live in
+// the patch's column.  Tile block entry j <-> patch entry spectralIndexL - 1 + j; a tile OWNS the first num_cells entries
+// of each (z-mode, wavenumber block) - the last tile all num_cells + 3 - and SENDS the remaining 3 to the next tile.
+static void index_maps(const sx_handle *h, std::vector<int64_t> &po, std::vector<int64_t> &to, std::vector<int64_t> &ph,
+                       std::vector<int64_t> &th) {
+    const bool last = (h->cell0 + h->ncells == h->nc);
+    const int owned = h->ncells + (last ? 3 : 0);
+    for (int zm = 0; zm < h->Zb; zm++)
+        for (int blk = 0; blk < h->K2t; blk++) {
+            for (int j = 0; j < owned; j++) {
+                po.push_back(1 + ref_index(zm, blk, h->cell0 + j, h->K2ref, h->b_rDim));
+                to.push_back(1 + ref_index(zm, blk, j, h->K2t, h->nbt));
+            }
+            for (int j = owned; j < h->nbt; j++) {
+                ph.push_back(1 + ref_index(zm, blk, h->cell0 + j, h->K2ref, h->b_rDim));
+                th.push_back(1 + ref_index(zm, blk, j, h->K2t, h->nbt));
+            }
+        }
+}
+
+int sx_index_map_sizes(const sx_handle *h, int64_t *n_owned, int64_t *n_halo) {
+    clear_error();
+    if (!h || !n_owned || !n_halo) { set_error("null argument"); return 1; }
+    const bool last = (h->cell0 + h->ncells == h->nc);
+    const int64_t blocks = (int64_t)h->Zb * h->K2t;
+    *n_owned = blocks * (h->ncells + (last ? 3 : 0));
+    *n_halo = blocks * (last ? 0 : 3);
+    return 0;
+}
+
+int sx_index_maps(const sx_handle *h, int64_t *patch_owned, int64_t *tile_owned, int64_t *patch_halo, int64_t *tile_halo) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    std::vector<int64_t> po, to, ph, th;
+    index_maps(h, po, to, ph, th);
+    if (patch_owned) std::copy(po.begin(), po.end(), patch_owned);
+    if (tile_owned) std::copy(to.begin(), to.end(), tile_owned);
+    if (patch_halo) std::copy(ph.begin(), ph.end(), patch_halo);
+    if (tile_halo) std::copy(th.begin(), th.end(), tile_halo);
+    return 0;
 }
 
 int sx_spectral_transform(sx_handle *h) {

@@ -1,0 +1,207 @@
+// Tile <-> patch exchange over RCCL, inside the library (include/scythe_hip.h "exchange over RCCL").
+//
+// The reference moves the 3-coefficient halo through a RemoteChannel chain and sums the tiles' B coefficients in a
+// SharedArray on the master (src/semiimplicit.jl:203-219, 320-329, 272-282), then every worker solves the whole patch
+// (:285).  Here one process owns one GPU and one tile; the exchange runs on the handle's stream with ncclSend / ncclRecv /
+// ncclAllGather, so a host in any language (the Julia glue of INTEGRATION.md) needs nothing but ccall - no torch.
+// librccl is bound at first use with dlopen: a single-GPU user never loads it.
+#include "sx_internal.hpp"
+#include <dlfcn.h>
+#include <cstdlib>
+#include <cstring>
+
+namespace sx {
+
+// the parts of rccl.h this file uses (ABI of RCCL 2.x: /opt/rocm/include/rccl/rccl.h:40-43, 187, 220, 260, 339, 467, 678-722, 923-933)
+struct NcclUniqueId { char internal[128]; };
+typedef void *NcclComm;
+enum { NCCL_DOUBLE = 8 };
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(NcclUniqueId *) = nullptr;
+    int (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*Send)(const void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, NcclComm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+};
+
+static Rccl *rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r.lib ? &r : nullptr;
+    tried = true;
+    const char *names[] = {getenv("SX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // a copy that is already mapped (e.g. the one PyTorch ships) wins: one RCCL per process
+    for (const char *n : names)
+        if (n && !r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    for (const char *n : names)
+        if (n && !r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.lib) { set_error(std::string("librccl not found: ") + dlerror()); return nullptr; }
+#define BIND(field, sym)                                                                  \
+    *(void **)(&r.field) = dlsym(r.lib, sym);                                             \
+    if (!r.field) { set_error(std::string("librccl lacks ") + sym); r.lib = nullptr; return nullptr; }
+    BIND(GetUniqueId, "ncclGetUniqueId") BIND(CommInitRank, "ncclCommInitRank") BIND(CommDestroy, "ncclCommDestroy")
+    BIND(GetErrorString, "ncclGetErrorString") BIND(Send, "ncclSend") BIND(Recv, "ncclRecv") BIND(AllGather, "ncclAllGather")
+    BIND(GroupStart, "ncclGroupStart") BIND(GroupEnd, "ncclGroupEnd")
+#undef BIND
+    return &r;
+}
+
+#define NCCLOK(call)                                                                       \
+    do {                                                                                   \
+        const int rc_ = (call);                                                            \
+        if (rc_ != 0) { set_error(std::string(#call) + ": " + R->GetErrorString(rc_)); return 1; }   \
+    } while (0)
+
+struct CommState {
+    NcclComm comm = nullptr;
+    bool owned = false;            // created by sx_comm_init (destroyed with the handle) vs attached by the host
+    int n = 0, me = 0, mode = -1;  // mode 0: transposed solve (all-to-all), 1: halo + all-gather + redundant solve
+    std::vector<int> cell0, ncells;
+    // a2a: tile side [dest d][row][cw[d]], owner side [tile t][row][cw[me]]
+    std::vector<int64_t> tile_off, tile_cnt, own_off, own_cnt;
+    double *tile_buf = nullptr, *tile_buf2 = nullptr, *own_in = nullptr, *own_out = nullptr;
+    // gather: [tile][max_rows][C] + the 3 received halo rows
+    double *gbuf = nullptr, *halo = nullptr;
+    int64_t max_rows = 0;
+};
+
+static bool dev_alloc(sx_handle *h, double **p, int64_t n) {
+    void *d = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)std::max<int64_t>(n, 1);
+    if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess) { set_error("hipMalloc failed (exchange buffers)"); return false; }
+    h->allocs.push_back(d);
+    h->dev_bytes += bytes;
+    *p = (double *)d;
+    return true;
+}
+
+void comm_release(sx_handle *h) {
+    CommState *c = (CommState *)h->comm_state;
+    if (!c) return;
+    if (c->owned && c->comm) { Rccl *R = rccl(); if (R) R->CommDestroy(c->comm); }
+    delete c;
+    h->comm_state = nullptr;
+}
+
+}  // namespace sx
+
+using namespace sx;
+
+extern "C" {
+
+int sx_comm_unique_id(char *out128) {
+    clear_error();
+    Rccl *R = rccl();
+    if (!R || !out128) return 1;
+    NcclUniqueId id;
+    NCCLOK(R->GetUniqueId(&id));
+    std::memcpy(out128, id.internal, 128);
+    return 0;
+}
+
+static int configure(sx_handle *h, CommState *c, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode) {
+    if (mode != 0 && mode != 1) { set_error("exchange mode must be 0 (all-to-all) or 1 (gather)"); return 1; }
+    c->n = n; c->me = me; c->mode = mode;
+    c->cell0.assign(cell0, cell0 + n);
+    c->ncells.assign(ncells, ncells + n);
+    if (mode == 0) {
+        if (sx_a2a_configure(h, n, me, cell0, ncells)) return 1;
+        std::vector<int64_t> cs(n + 1);
+        if (sx_a2a_col_starts(h, cs.data())) return 1;
+        c->tile_off.assign(n, 0); c->tile_cnt.assign(n, 0); c->own_off.assign(n, 0); c->own_cnt.assign(n, 0);
+        int64_t to = 0, oo = 0;
+        for (int d = 0; d < n; d++) {
+            c->tile_off[d] = to; c->tile_cnt[d] = (int64_t)(ncells[me] + 3) * (cs[d + 1] - cs[d]); to += c->tile_cnt[d];
+            c->own_off[d] = oo; c->own_cnt[d] = (int64_t)(ncells[d] + 3) * (cs[me + 1] - cs[me]); oo += c->own_cnt[d];
+        }
+        if (!dev_alloc(h, &c->tile_buf, to) || !dev_alloc(h, &c->tile_buf2, to) || !dev_alloc(h, &c->own_in, oo) || !dev_alloc(h, &c->own_out, oo)) return 1;
+    } else {
+        if (cell0[me] != h->cell0 || ncells[me] != h->ncells) { set_error("tile table does not match this handle"); return 1; }
+        c->max_rows = 0;
+        for (int t = 0; t < n; t++) c->max_rows = std::max<int64_t>(c->max_rows, ncells[t] + 3);
+        if (!dev_alloc(h, &c->gbuf, (int64_t)n * c->max_rows * h->C) || !dev_alloc(h, &c->halo, 3 * h->C)) return 1;
+        std::vector<int64_t> ro(h->b_rDim, 0);
+        for (int t = 0; t < n; t++) {
+            const int owned = ncells[t] + (t == n - 1 ? 3 : 0);
+            for (int j = 0; j < owned; j++) ro[cell0[t] + j] = ((int64_t)t * c->max_rows + j) * h->C;
+        }
+        if (sx_bind_tile_b(h, c->gbuf + (int64_t)me * c->max_rows * h->C)) return 1;
+        if (sx_bind_patch_b(h, c->gbuf, ro.data())) return 1;
+    }
+    return 0;
+}
+
+int sx_comm_init(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode, const char *id128) {
+    clear_error();
+    if (!h || !cell0 || !ncells || !id128 || n < 1 || me < 0 || me >= n) { set_error("sx_comm_init: invalid argument"); return 1; }
+    Rccl *R = rccl();
+    if (!R) return 1;
+    comm_release(h);
+    CommState *c = new CommState();
+    h->comm_state = c;
+    if (configure(h, c, n, me, cell0, ncells, mode)) return 1;
+    NcclUniqueId id;
+    std::memcpy(id.internal, id128, 128);
+    NCCLOK(R->CommInitRank(&c->comm, n, id, me));      // collective over the n tiles; uses the calling thread's current device
+    c->owned = true;
+    return 0;
+}
+
+int sx_comm_attach(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode, void *nccl_comm) {
+    clear_error();
+    if (!h || !cell0 || !ncells || !nccl_comm || n < 1 || me < 0 || me >= n) { set_error("sx_comm_attach: invalid argument"); return 1; }
+    if (!rccl()) return 1;
+    comm_release(h);
+    CommState *c = new CommState();
+    h->comm_state = c;
+    if (configure(h, c, n, me, cell0, ncells, mode)) return 1;
+    c->comm = nccl_comm;
+    c->owned = false;
+    return 0;
+}
+
+int sx_exchange(sx_handle *h) {
+    clear_error();
+    if (!h || !h->comm_state) { set_error("sx_exchange: call sx_comm_init / sx_comm_attach first"); return 1; }
+    CommState *c = (CommState *)h->comm_state;
+    Rccl *R = rccl();
+    if (!R) return 1;
+    const int n = c->n, me = c->me;
+    hipStream_t s = h->stream;
+    if (c->mode == 0) {
+        // transposed solve: B rows -> owners of the column ranges, solve my columns for the whole patch, A rows back
+        if (sx_a2a_pack_b(h, c->tile_buf)) return 1;
+        NCCLOK(R->GroupStart());
+        for (int d = 0; d < n; d++) {
+            NCCLOK(R->Send(c->tile_buf + c->tile_off[d], (size_t)c->tile_cnt[d], NCCL_DOUBLE, d, c->comm, s));
+            NCCLOK(R->Recv(c->own_in + c->own_off[d], (size_t)c->own_cnt[d], NCCL_DOUBLE, d, c->comm, s));
+        }
+        NCCLOK(R->GroupEnd());
+        if (sx_a2a_solve(h, c->own_in, c->own_out)) return 1;
+        NCCLOK(R->GroupStart());
+        for (int t = 0; t < n; t++) {
+            NCCLOK(R->Send(c->own_out + c->own_off[t], (size_t)c->own_cnt[t], NCCL_DOUBLE, t, c->comm, s));
+            NCCLOK(R->Recv(c->tile_buf2 + c->tile_off[t], (size_t)c->tile_cnt[t], NCCL_DOUBLE, t, c->comm, s));
+        }
+        NCCLOK(R->GroupEnd());
+        return sx_a2a_unpack_a(h, c->tile_buf2);
+    }
+    // the reference's protocol: halo rows tile -> tile + 1 (:320-329), owned rows to everybody (:272-282), redundant solve (:285)
+    double *mine = c->gbuf + (int64_t)me * c->max_rows * h->C;
+    if (n > 1) {
+        NCCLOK(R->GroupStart());
+        if (me < n - 1) NCCLOK(R->Send(mine + (int64_t)c->ncells[me] * h->C, (size_t)(3 * h->C), NCCL_DOUBLE, me + 1, c->comm, s));
+        if (me > 0) NCCLOK(R->Recv(c->halo, (size_t)(3 * h->C), NCCL_DOUBLE, me - 1, c->comm, s));
+        NCCLOK(R->GroupEnd());
+        if (me > 0 && sx_halo_add(h, c->halo)) return 1;
+    }
+    NCCLOK(R->AllGather(mine, c->gbuf, (size_t)(c->max_rows * h->C), NCCL_DOUBLE, c->comm, s));     // in place: my block is my slot
+    return sx_spline_transform(h);
+}
+
+}  // extern "C"

@@ -132,6 +132,7 @@ struct sx_handle {
     double *d_r = nullptr, *d_cosl = nullptr, *d_sinl = nullptr, *d_z = nullptr;
     int *d_flag = nullptr;
     unsigned long long *d_maxabs = nullptr;   // [V] scratch of sx_max_abs
+    void *comm_state = nullptr;               // RCCL exchange state (sx_comm.cpp)
     int *d_mask_full = nullptr, *d_mask_eq = nullptr;   // per-variable bit masks of derivative slots to produce
     int mask_eq_bits = 0, mask_full_bits = 0;            // total number of (variable, slot) planes in each mask
     int mask_eq_val = 0, mask_full_val = 0, mask_node_val = 0;   // of which value-slot planes (always fp64)
@@ -182,4 +183,6 @@ void timer_begin(sx_handle *h, int id);
 void timer_end(sx_handle *h);
 void timers_flush(sx_handle *h);
 void set_error(const std::string &msg);
+void clear_error();
+void comm_release(sx_handle *h);
 }  // namespace sx

@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-from .model import (Grid, GridParameters, ModelParameters, calcTileSizes, checkCFL, getGridpoints)
+from .model import (Grid, GridParameters, ModelParameters, calcTileSizes, checkCFL, comm_unique_id, getGridpoints)
 
 
 class PatchLayout:
@@ -238,13 +238,41 @@ class DistA2AExchange:
         (unpack or (lambda b: self.tile.a2a_unpack_a(b.data_ptr())))(self.tile_buf2)
 
 
+class LibExchange:
+    """One tile per rank, exchange done INSIDE libscythe_hip.so with RCCL on the tile's stream (sx_comm_init / sx_exchange):
+    what a Julia host would use.  Only the 128-byte ncclUniqueId travels through the host-side launcher - here
+    torch.distributed's store (any backend), in the reference's world the master's RemoteChannels."""
+
+    def __init__(self, layout: PatchLayout, tile: Grid, mode, group=None, unique_id=None):
+        self.tile, self.mode = tile, mode
+        rank, world = 0, 1
+        if unique_id is None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            box = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            unique_id = box[0]
+        else:
+            rank = layout.cell0.index(tile.cell0) if layout.num_tiles > 1 else 0
+            world = layout.num_tiles
+        assert world == layout.num_tiles
+        self.rank, self.world = rank, world
+        tile.comm_init(layout.cell0, layout.ncells, rank, mode, unique_id)
+
+    def exchange_and_solve(self):
+        self.tile.exchange()
+
+
 class ModelRun:
     """initialize_model + run_model state for one process (src/semiimplicit.jl:126-256)."""
 
     def __init__(self, model: ModelParameters, num_tiles=1, rank=None, device=None, use_dist=False, exchange="a2a",
-                 split="reference"):
+                 split="reference", impl="torch", unique_id=None):
         """exchange: "a2a" = transposed solve over all-to-all (scales), "gather" = the reference's protocol
-        (halo chain + gather of owned rows + redundant patch solve on every tile)."""
+        (halo chain + gather of owned rows + redundant patch solve on every tile).
+        impl (use_dist only): "lib" = RCCL calls inside libscythe_hip.so on the tile's stream (sx_exchange; also valid with
+        ONE tile, where every send is a send to self - the one-GPU self-test of that code path), "torch" =
+        torch.distributed collectives on device tensors (also what the gloo rehearsals use)."""
         self.model = model
         patch = model.grid_params
         self.patch = patch
@@ -261,7 +289,12 @@ class ModelRun:
             self.tile_ids = list(range(num_tiles))
         self.exchange = None
         self.exchange_kind = exchange if num_tiles > 1 else "none"
-        if num_tiles > 1:
+        self.impl = impl if use_dist else "local"
+        self._bind_streams(device)
+        if use_dist and impl == "lib":
+            self.exchange_kind = exchange
+            self.exchange = LibExchange(self.layout, self.tiles[0], exchange, unique_id=unique_id)
+        elif num_tiles > 1:
             if exchange == "a2a":
                 self.exchange = (DistA2AExchange(self.layout, self.tiles[0], device) if use_dist
                                  else LocalA2AExchange(self.layout, self.tiles, device))
@@ -271,6 +304,27 @@ class ModelRun:
             else:
                 raise ValueError("exchange must be 'a2a' or 'gather'")
         self.t = 0
+
+    def _bind_streams(self, device):
+        """Kernels of a tile run on ITS stream; torch's collectives order themselves against torch's CURRENT stream.  Hand
+        that stream to the library so that both see one queue (with the default stream this is stream 0, as before)."""
+        self._stream = None
+        try:
+            torch = _torch()
+            if device is not None and torch.cuda.is_available():
+                self._stream = torch.cuda.current_stream(device).cuda_stream
+                for g in self.tiles:
+                    g.set_stream(self._stream)
+        except ImportError:
+            pass
+
+    def _check_stream(self):
+        if self._stream is not None and self.impl == "torch":
+            cur = _torch().cuda.current_stream().cuda_stream
+            if cur != self._stream:          # the caller entered a torch.cuda.stream(...) context: follow it
+                self._stream = cur
+                for g in self.tiles:
+                    g.set_stream(cur)
 
     def tile_points(self, t):
         return self.tiles[self.tile_ids.index(t)].N
@@ -283,6 +337,10 @@ class ModelRun:
         self._exchange_and_solve()
 
     def _exchange_and_solve(self):
+        self._check_stream()
+        if self.impl == "lib":
+            self.exchange.exchange_and_solve()
+            return
         if self.exchange_kind == "a2a":
             self.exchange.exchange_and_solve()
             return

@@ -387,6 +387,28 @@ class Grid:
     def a2a_unpack_a(self, dev_recv):
         L.check(self._lib.sx_a2a_unpack_a(self._h, C.c_void_p(dev_recv)))
 
+    def index_maps(self):
+        """calcPatchMap / calcHaloMap (src/semiimplicit.jl:79-86): 1-based linear indices into one variable's column:
+        (patch_owned, tile_owned, patch_halo, tile_halo)."""
+        no, nh = C.c_int64(), C.c_int64()
+        L.check(self._lib.sx_index_map_sizes(self._h, C.byref(no), C.byref(nh)))
+        a = [np.zeros(n, dtype=np.int64) for n in (no.value, no.value, nh.value, nh.value)]
+        L.check(self._lib.sx_index_maps(self._h, *[x.ctypes.data_as(L.P_I64) for x in a]))
+        return tuple(a)
+
+    # -- exchange over RCCL inside the library (sx_comm.cpp)
+    def comm_init(self, cell0, ncells, my_tile, mode, unique_id):
+        """Collective over all tiles: ncclCommInitRank on this tile's device + exchange buffers. mode "a2a" or "gather"."""
+        n = len(cell0)
+        c0 = (C.c_int32 * n)(*cell0)
+        nc = (C.c_int32 * n)(*ncells)
+        assert len(unique_id) == 128
+        L.check(self._lib.sx_comm_init(self._h, n, my_tile, c0, nc, {"a2a": 0, "gather": 1}[mode], bytes(unique_id)))
+
+    def exchange(self):
+        """Halo / shared sum / patch solve of one step on the handle's stream (src/semiimplicit.jl:320-329, 272-285)."""
+        L.check(self._lib.sx_exchange(self._h))
+
     # -- timers
     def enable_timers(self, on=True):
         L.check(self._lib.sx_enable_timers(self._h, int(on)))
@@ -406,6 +428,13 @@ class Grid:
         b = C.c_double(0.0)
         L.check(self._lib.sx_kernel_bytes(self._h, name.encode(), C.byref(b)))
         return b.value
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library: 128 bytes that rank 0 hands to every other rank before Grid.comm_init."""
+    buf = C.create_string_buffer(128)
+    L.check(L.load().sx_comm_unique_id(buf))
+    return buf.raw
 
 
 def createGrid(gp: GridParameters, model: Optional[ModelParameters] = None):

@@ -16,7 +16,7 @@ def test_config2_rl_slab_literal_100_cells():
     case = cases.config2_literal()
     hip = cases.HipModel(case)
     orc = cases.OracleModel(case)
-    alt = cases.OracleModel(case, tiles=[(0, 70), (70, 30)])
+    alt = cases.OracleModel(case, numpy_twin=True)
     assert hip.run.tiles[0].N == 181800
     for _ in range(3):
         hip.step()
@@ -62,7 +62,7 @@ def test_config3_rz_513x128_semiimplicit_three_way():
         ext.step()
         lu.step()
     rings = list(range(0, 513, 19))
-    alt = cases.OracleModel(case, tiles=[(0, 100), (100, 71)])
+    alt = cases.OracleModel(case, numpy_twin=True)
     for _ in range(6):
         alt.step()
     _check(hip, ext, rings, "config 3 (RZ 513 x 128, semi-implicit), 6 steps, HIP vs extended-precision Helmholtz oracle", orc_alt=alt)

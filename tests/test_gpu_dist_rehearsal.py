@@ -1,12 +1,15 @@
 """-m gpu: two ranks on the one GPU, torch.distributed over gloo (device buffers staged through the host): the
 whole multi-rank step path of bench.py - tile per rank, pack / all-to-all / solve / all-to-all / unpack, or halo +
-all-gather - against the one-patch oracle. RCCL itself cannot be exercised on a one-GPU box."""
+all-gather - against the one-patch oracle; the in-library RCCL exchange with a one-rank communicator on the one GPU
+(RCCL refuses two ranks on one device) and, where two GPUs exist, bench.py over RCCL with its exchange self-check."""
 import os
 import socket
 
 import numpy as np
 import pytest
 import torch.multiprocessing as mp
+
+from tests import cases
 
 pytestmark = pytest.mark.gpu
 
@@ -106,3 +109,55 @@ def test_bench_cli_two_ranks_on_one_device():
         assert key in d, key
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["nan"] is False
     assert d["config"]["exchange"] == "a2a" and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange", ["a2a", "gather"])
+@pytest.mark.parametrize("maker,kw", [(cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}), (cases.rl_slab, {"num_cells": 9}),
+                                       (cases.rz_semiimplicit, {"num_cells": 9})])
+def test_in_library_rccl_exchange_world_size_one(maker, kw, exchange):
+    """sx_comm_init / sx_exchange with a ONE-rank RCCL communicator on the one GPU: the whole code path of the in-library
+    exchange (dlopen of librccl, ncclCommInitRank, grouped ncclSend / ncclRecv to self or the in-place ncclAllGather, pack /
+    solve / unpack on the handle's stream) against the plain single-tile run.  RCCL refuses two ranks on one device, so
+    more ranks need more GPUs (next test)."""
+    import scythe_jl_amd as S
+    case = maker(**kw)
+    ref = cases.HipModel(case)
+    gp, mp = cases.hip_params(case)
+    run = S.ModelRun(mp, num_tiles=1, rank=0, device="cuda", use_dist=True, exchange=exchange, impl="lib",
+                     unique_id=S.comm_unique_id())
+    pts = S.getGridpoints(run.tiles[0])
+    run.set_initial_conditions([case["ic"](pts.reshape(len(pts), -1))])
+    for _ in range(4):
+        ref.step()
+        run.step()
+    a, b = run.physical(), ref.physical()
+    assert np.isfinite(a).all()
+    assert cases.rel_err_per_var(a, b) < 1e-12
+    run.close()
+
+
+@pytest.mark.gpu
+def test_bench_cli_two_ranks_rccl():
+    """N = 2 over RCCL on two GPUs (skipped on the one-GPU box): bench.py's self-check steps the in-library exchange and the
+    torch.distributed one side by side and reports their largest relative difference."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    for exchange in ("a2a", "gather"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+               "--workload", "rlz_small", "--exchange", exchange]
+        out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange_impl"] == "lib"
+        assert d["config"]["exchange_selfcheck_max_rel_diff"] < 1e-12
