@@ -582,6 +582,9 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
 int sx_destroy(sx_handle *h) {
     if (!h) return 0;
     hipDeviceSynchronize();
+#ifdef SX_PHASES
+    phases_dump();
+#endif
     comm_release(h);
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->event_pool) hipEventDestroy(e);

@@ -185,4 +185,7 @@ void timers_flush(sx_handle *h);
 void set_error(const std::string &msg);
 void clear_error();
 void comm_release(sx_handle *h);
+#ifdef SX_PHASES
+void phases_dump();
+#endif
 }  // namespace sx

@@ -712,6 +712,12 @@ struct PhysArgsT {
                           // stand-alone sx_physics needs it there; inside sx_advance nothing reads that plane again
     int64_t NG;
     int L, nrings;
+    // cell-independent constants of the cell-wise kernel (scalar registers, no loads): basis weights phi / phi' / phi'' of a
+    // cell's 3 Gauss points at its 4 nodes, and what it takes to recompute r exactly as sx_create tabulates it
+    double phiw[3][MUBAR][4];
+    double xmin, DX, goff[MUBAR];
+    int gcell0;           // patch index of the tile's first cell
+    long long *dbg;       // phase stamps [workgroup][8] of the diagnostic build (-DSX_PHASES, profiles/phases.sh); otherwise null
 };
 
 // A diagnostic variable has expdot == 0 for ever (src/shallowWaterModels.jl:69, 185, 430): explicit_timestep reduces to
@@ -1093,29 +1099,33 @@ __global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
     for (int v = 6; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
 }
 
-// 16 bytes per lane for streams that are 8 bytes per point.  The vector-memory pipe of a CU moves 8-byte-per-lane accesses
-// at about half the rate of 16-byte ones (MI355X_MICROARCH.md: "8-B accesses 0.54-0.70x the 16-B rate", "16 x dwordx2 per
-// lane ... store-ISSUE-bound"), and the equation-set kernels issue ~120 of them per thread.  A wave owns 64 consecutive
-// doubles of every stream; lanes 0-31 fetch TWO consecutive elements of stream a, lanes 32-63 of stream b, and one
-// v_permlane32_swap per dword leaves (a[e], b[e]) in every lane with e = 2 (lane & 31) + (lane >> 5) - which is therefore
-// the element (level) a lane works on.  Stores run the same exchange backwards.  pa / pb already point at the lane's pair.
+// 16 bytes per lane for streams that are 8 bytes per point.  A wave owns 64 consecutive doubles of every stream; lanes
+// 0-31 fetch TWO consecutive elements of stream a, lanes 32-63 of stream b (one global_load_dwordx4 instead of two
+// dwordx2), and one v_permlane32_swap per dword leaves (a[e], b[e]) in every lane with e = 2 (lane & 31) + (lane >> 5) -
+// which is therefore the element (level) a lane works on.  Stores run the same exchange backwards.  The load and the
+// exchange are SEPARATE steps (RawPair): an exchange right behind its load makes the wave wait for that load alone, and a
+// handful of such round trips in a row was most of this kernel's time (phase stamps, profiles/r02/phases_*.txt).
 typedef double dbl2v __attribute__((ext_vector_type(2)));
 typedef float flt2v __attribute__((ext_vector_type(2)));
+template <class T> struct Vec2;
+template <> struct Vec2<double> { typedef dbl2v type; };
+template <> struct Vec2<float> { typedef flt2v type; };
 __device__ __forceinline__ int wide_elem(int lane) { return 2 * (lane & 31) + (lane >> 5); }
 
-template <bool NT>
-__device__ __forceinline__ void load_pair(const double *pa, const double *pb, int lane, double &xa, double &xb) {
-    const dbl2v *p = reinterpret_cast<const dbl2v *>(lane < 32 ? pa : pb);
-    const dbl2v t = NT ? __builtin_nontemporal_load(p) : *p;
+// pa / pb point at the lane's pair of stream a / b
+template <bool NT, class T>
+__device__ __forceinline__ typename Vec2<T>::type issue_pair(const T *pa, const T *pb, int lane) {
+    typedef typename Vec2<T>::type V;
+    const V *p = reinterpret_cast<const V *>(lane < 32 ? pa : pb);
+    return NT ? __builtin_nontemporal_load(p) : *p;
+}
+__device__ __forceinline__ void take_pair(dbl2v t, double &xa, double &xb) {
     const auto r0 = __builtin_amdgcn_permlane32_swap(__double2loint(t.x), __double2loint(t.y), false, false);
     const auto r1 = __builtin_amdgcn_permlane32_swap(__double2hiint(t.x), __double2hiint(t.y), false, false);
     xa = __hiloint2double(r1[0], r0[0]);
     xb = __hiloint2double(r1[1], r0[1]);
 }
-template <bool NT>
-__device__ __forceinline__ void load_pair(const float *pa, const float *pb, int lane, double &xa, double &xb) {
-    const flt2v *p = reinterpret_cast<const flt2v *>(lane < 32 ? pa : pb);
-    const flt2v t = NT ? __builtin_nontemporal_load(p) : *p;
+__device__ __forceinline__ void take_pair(flt2v t, double &xa, double &xb) {
     const auto r0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(t.x), __float_as_uint(t.y), false, false);
     xa = (double)__uint_as_float(r0[0]);
     xb = (double)__uint_as_float(r0[1]);
@@ -1130,13 +1140,27 @@ __device__ __forceinline__ void store_pair_nt(double *pa, double *pb, int lane, 
     __builtin_nontemporal_store(t, reinterpret_cast<dbl2v *>(lane < 32 ? pa : pb));
 }
 
+// In-kernel phase stamps (s_memtime) of the diagnostic build only; the stamps go to a buffer nothing else reads.
+#ifdef SX_PHASES
+#define SX_STAMP(i) do { if (threadIdx.x == 0 && a.dbg) a.dbg[(int64_t)blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define SX_STAMP(i) do { } while (0)
+#endif
+// keeps the loads in front of it in front of the loads behind it (the memory counter retires in issue order: what is
+// needed first must be issued first)
+#define SX_LOAD_FENCE() asm volatile("" ::: "memory")
+
 // Cell-wise node-space variant ("radial last", uniform rings): one workgroup = LAM azimuths x NZ levels of ONE radial
 // cell, i.e. the 3 rings that share the same 4 spline nodes.  Each thread loads the 14 node transforms of its
 // (lambda, z) at the 4 nodes once (56 values, kept in registers) and evaluates all 3 rings from them, so a node value
 // enters the CU once instead of three times (the ring-wise grouping was bound by L1 fill rate, not by HBM).
 // The column operators of the 3 x LAM columns run as one f64-MFMA batch; the fields are re-formed from the registers
 // after it, ring by ring, for the tendencies.
-// WIDE: 16-byte-per-lane loads / stores with the lane <-> level map of load_pair (needs 64 | LAM * NZ, always true here).
+// Load schedule (what the phase stamps asked for): every load a workgroup needs is issued in ONE burst at entry, oldest =
+// needed first; nothing small is fetched on its own later.  The per-ring constants come without memory traffic: the
+// basis weights phi / phi' / phi'' at a cell's three Gauss points are the same for every cell (kernel arguments, scalar
+// registers) and r is recomputed from the cell index exactly as sx_create tabulates it.
+// WIDE: 16-byte-per-lane loads / stores with the lane <-> level map of issue_pair (needs 64 | LAM * NZ, always true here).
 template <int NZ, int LAM, class ST, bool WIDE>
 __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a, int cell0) {
     constexpr int CS = NZ + 2;
@@ -1147,6 +1171,7 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     __shared__ double Ysep[ALIAS ? 1 : 3][ALIAS ? 1 : NT * 16 * CS];
     double (*Y)[NT * 16 * CS] = ALIAS ? X : reinterpret_cast<double (*)[NT * 16 * CS]>(&Ysep[0][0]);
     __shared__ double s1[2][NCOL];
+    SX_STAMP(0);
     const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
     const int elem = WIDE ? wbase + wide_elem(lane) : (int)threadIdx.x;      // element of the workgroup's LAM x NZ block
     const int k = elem % NZ, ll = elem / NZ;
@@ -1159,87 +1184,76 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     const double g = par[SX_P_G], Kh = par[SX_P_KH], Hfree = par[SX_P_HFREE], f = par[SX_P_F];
     const int64_t gp = ((int64_t)cell * a.L + lam) * NZ + k;
     const int64_t gs = (int64_t)a.L * NZ;
-    // per-ring constants of the final phase (phi, phi', phi'' weights and 1 / r) go through LDS once, so that the three ring
-    // passes after the column operators do not each wait for their own scalar loads
-    __shared__ double sphi[MUBAR][12], srinv[MUBAR];
-    if (threadIdx.x < MUBAR * 12) {
-        const int mu = threadIdx.x / 12, e = threadIdx.x % 12;
-        sphi[mu][e] = a.phi[((int64_t)(e / 4) * a.nrings + cell * MUBAR + mu) * 4 + (e % 4)];
-    } else if (threadIdx.x < MUBAR * 13) {
-        const int mu = threadIdx.x - MUBAR * 12;
-        srinv[mu] = 1.0 / a.r[(int64_t)(cell * MUBAR + mu) * a.L];
-    }
-    // the surface-drag lanes (k < 3: one ring each) fetch their cos / sin(lambda) now, with everything else
+    const int64_t gw = (int64_t)cell * a.L * NZ + pairo;                      // this lane's pair at node 0 of the cell
+    const int64_t pc = ((int64_t)(cell * MUBAR) * a.L + lam) * NZ + k;        // this lane's point on ring mu = 0; + mu * gs
+    const int64_t pw = (int64_t)(cell * MUBAR) * a.L * NZ + pairo;            // this lane's pair on ring mu = 0
+
+    // ---- the one burst of loads, oldest first: level height and surface-drag angles (one small load each, L2-resident)
+    const double zk = a.z[k];
     double cs_d = 0.0, sn_d = 0.0;
-    if (k < MUBAR) {
+    if (k < MUBAR) {       // the surface-drag lanes (k < 3: one ring each)
         const int64_t col = (int64_t)(cell * MUBAR + k) * a.L + lam;
         cs_d = a.cosl[col]; sn_d = a.sinl[col];
     }
-    // node transforms: [transform][node]
+    // node transforms [transform][node].  WIDE keeps the raw 16-byte pairs (nodes 0|1 and 2|3) until they are needed.
+    typedef typename Vec2<ST>::type SV;
     double qh[4], qhl[4], qug[4], qugl[4], qvg[4], qvgl[4];
     double qub[4], qubl[4], qubll[4], qubz[4], qvb[4], qvbl[4], qvbll[4], qvbz[4];
-#define GLOADV(dst, v)                                                                             \
+    dbl2v rv[5][2];         // value planes: ub, vb | h, ug, vg
+    SV rd[9][2];            // derivative planes: ubz, vbz, vbl | hl, ugl, vgl, ubl, ubll, vbll
+#define NODE_V(dst, raw, v)                                                                        \
     {                                                                                              \
-        const double *gq = a.G.val + (int64_t)(v) * a.NG + gp;                                     \
-        dst[0] = gq[0]; dst[1] = gq[gs]; dst[2] = gq[2 * gs]; dst[3] = gq[3 * gs];                 \
+        const double *gq = a.G.val + (int64_t)(v) * a.NG;                                          \
+        if (WIDE) { raw[0] = issue_pair<false>(gq + gw, gq + gw + gs, lane); raw[1] = issue_pair<false>(gq + gw + 2 * gs, gq + gw + 3 * gs, lane); } \
+        else { dst[0] = gq[gp]; dst[1] = gq[gp + gs]; dst[2] = gq[gp + 2 * gs]; dst[3] = gq[gp + 3 * gs]; } \
     }
-#define GLOAD(dst, v, s)                                                                           \
+#define NODE_D(dst, raw, v, s)                                                                     \
     {                                                                                              \
-        const ST *gq = a.G.der + ((int64_t)((s) - 1) * a.V + (v)) * a.NG + gp;                     \
-        dst[0] = gq[0]; dst[1] = gq[gs]; dst[2] = gq[2 * gs]; dst[3] = gq[3 * gs];                 \
+        const ST *gq = a.G.der + ((int64_t)((s) - 1) * a.V + (v)) * a.NG;                          \
+        if (WIDE) { raw[0] = issue_pair<false>(gq + gw, gq + gw + gs, lane); raw[1] = issue_pair<false>(gq + gw + 2 * gs, gq + gw + 3 * gs, lane); } \
+        else { dst[0] = gq[gp]; dst[1] = gq[gp + gs]; dst[2] = gq[gp + 2 * gs]; dst[3] = gq[gp + 3 * gs]; } \
     }
-    const int64_t gw = (int64_t)cell * a.L * NZ + pairo;       // this lane's pair at node 0 of the cell
-#define WLOADV(dst, v)                                                                             \
-    {                                                                                              \
-        const double *gq = a.G.val + (int64_t)(v) * a.NG + gw;                                     \
-        load_pair<false>(gq, gq + gs, lane, dst[0], dst[1]);                                       \
-        load_pair<false>(gq + 2 * gs, gq + 3 * gs, lane, dst[2], dst[3]);                          \
-    }
-#define WLOAD(dst, v, s)                                                                           \
-    {                                                                                              \
-        const ST *gq = a.G.der + ((int64_t)((s) - 1) * a.V + (v)) * a.NG + gw;                     \
-        load_pair<false>(gq, gq + gs, lane, dst[0], dst[1]);                                       \
-        load_pair<false>(gq + 2 * gs, gq + 3 * gs, lane, dst[2], dst[3]);                          \
-    }
-    if (WIDE) {
-        WLOADV(qub, 3) WLOAD(qubz, 3, a.s_z) WLOAD(qvbz, 4, a.s_z) WLOAD(qvbl, 4, a.s_l) WLOADV(qvb, 4)
-        WLOADV(qh, 0) WLOAD(qhl, 0, a.s_l) WLOADV(qug, 1) WLOAD(qugl, 1, a.s_l) WLOADV(qvg, 2) WLOAD(qvgl, 2, a.s_l)
-        WLOAD(qubl, 3, a.s_l) WLOAD(qubll, 3, a.s_ll) WLOAD(qvbll, 4, a.s_ll)
-    } else {
-        GLOADV(qub, 3) GLOAD(qubz, 3, a.s_z) GLOAD(qvbz, 4, a.s_z) GLOAD(qvbl, 4, a.s_l) GLOADV(qvb, 4)
-        GLOADV(qh, 0) GLOAD(qhl, 0, a.s_l) GLOADV(qug, 1) GLOAD(qugl, 1, a.s_l) GLOADV(qvg, 2) GLOAD(qvgl, 2, a.s_l)
-        GLOAD(qubl, 3, a.s_l) GLOAD(qubll, 3, a.s_ll) GLOAD(qvbll, 4, a.s_ll)
-    }
-#undef WLOAD
-#undef WLOADV
-#undef GLOAD
-#undef GLOADV
-    // tendency history of ring mu = 0, fetched now (latency hidden behind the operator phase); the next ring's is
-    // fetched while the current ring is finished
+#define NODE_TAKE(dst, raw) { if (WIDE) { take_pair(raw[0], dst[0], dst[1]); take_pair(raw[1], dst[2], dst[3]); } }
+    // what the column operators' inputs need ...
+    NODE_V(qub, rv[0], 3) NODE_D(qubz, rd[0], 3, a.s_z) NODE_D(qvbz, rd[1], 4, a.s_z) NODE_D(qvbl, rd[2], 4, a.s_l) NODE_V(qvb, rv[1], 4)
+    SX_LOAD_FENCE();
+    // ... then everything else, needed only after the column operators
+    NODE_V(qh, rv[2], 0) NODE_D(qhl, rd[3], 0, a.s_l) NODE_V(qug, rv[3], 1) NODE_D(qugl, rd[4], 1, a.s_l) NODE_V(qvg, rv[4], 2) NODE_D(qvgl, rd[5], 2, a.s_l)
+    NODE_D(qubl, rd[6], 3, a.s_l) NODE_D(qubll, rd[7], 3, a.s_ll) NODE_D(qvbll, rd[8], 4, a.s_ll)
+    // tendency history: ring 0 behind the operator fragments (in flight during the MFMA phase), rings 1 and 2 at the start
+    // of the final phase (in flight while ring 0 is finished) - fetched earlier it would only occupy registers.  WIDE:
+    // expdot_nm1 / nm2 of a variable travel as one pair; before step 3 the buffers exist but hold no history yet.
     double e1h[MUBAR][5], e2h[MUBAR][5];
-    const int64_t pc = ((int64_t)(cell * MUBAR) * a.L + lam) * NZ + k;      // ring mu = 0; + mu * L * NZ for the others
-    const int64_t pw = (int64_t)(cell * MUBAR) * a.L * NZ + pairo;            // this lane's pair on ring mu = 0
-    // WIDE: expdot_nm1 / nm2 of a variable travel as one pair; before step 3 the buffers exist but hold no history yet
+    dbl2v rh[MUBAR][5];
 #define HIST(mu)                                                                                   \
     _Pragma("unroll") for (int v = 0; v < 5; v++) {                                                \
         if (WIDE) {                                                                                \
-            if (a.t >= 2) {                                                                        \
-                load_pair<true>(a.E1 + (int64_t)v * a.N + pw + (mu) * gs, a.E2 + (int64_t)v * a.N + pw + (mu) * gs, lane, e1h[mu][v], e2h[mu][v]);   \
-                if (a.t < 3) e2h[mu][v] = 0.0;                                                     \
-            } else { e1h[mu][v] = 0.0; e2h[mu][v] = 0.0; }                                         \
+            if (a.t >= 2) rh[mu][v] = issue_pair<true>(a.E1 + (int64_t)v * a.N + pw + (mu) * gs, a.E2 + (int64_t)v * a.N + pw + (mu) * gs, lane);   \
         } else {                                                                                   \
             e1h[mu][v] = (a.t >= 2) ? __builtin_nontemporal_load(a.E1 + (int64_t)v * a.N + pc + (mu) * gs) : 0.0;   \
             e2h[mu][v] = (a.t >= 3) ? __builtin_nontemporal_load(a.E2 + (int64_t)v * a.N + pc + (mu) * gs) : 0.0;   \
         }                                                                                          \
     }
-    HIST(0)
+#define HIST_TAKE(mu)                                                                              \
+    _Pragma("unroll") for (int v = 0; v < 5; v++) {                                                \
+        if (WIDE) {                                                                                \
+            if (a.t >= 2) { take_pair(rh[mu][v], e1h[mu][v], e2h[mu][v]); if (a.t < 3) e2h[mu][v] = 0.0; }   \
+            else { e1h[mu][v] = 0.0; e2h[mu][v] = 0.0; }                                           \
+        }                                                                                          \
+    }
+    SX_LOAD_FENCE();
+
+    // ---- inputs of the column operators
+    NODE_TAKE(qub, rv[0]) NODE_TAKE(qubz, rd[0]) NODE_TAKE(qvbz, rd[1]) NODE_TAKE(qvbl, rd[2]) NODE_TAKE(qvb, rv[1])
 #define DOT(w, q) ((w)[0] * q[0] + (w)[1] * q[1] + (w)[2] * q[2] + (w)[3] * q[3])
-    const double lmix = 1.0 / ((1.0 / (0.4 * a.z[k])) + (1.0 / 80.0));
+    const double lmix = 1.0 / ((1.0 / (0.4 * zk)) + (1.0 / 80.0));
+    double rinv[MUBAR];
 #pragma unroll
     for (int mu = 0; mu < MUBAR; mu++) {
-        const int ring = cell * MUBAR + mu;
-        const double *w0 = a.phi + (int64_t)ring * 4, *w1 = w0 + (int64_t)a.nrings * 4;
-        const double ri = 1.0 / a.r[(int64_t)ring * a.L];
+        // r of the ring, as sx_create tabulates it (xmin + DX (c + 0.5 + offset of the Gauss point))
+        rinv[mu] = 1.0 / (a.xmin + a.DX * ((a.gcell0 + cell) + 0.5 + a.goff[mu]));
+        const double *w0 = a.phiw[0][mu], *w1 = a.phiw[1][mu];
+        const double ri = rinv[mu];
         const double ub = DOT(w0, qub), ubr = DOT(w1, qub), vbl = DOT(w0, qvbl), ubz = DOT(w0, qubz), vbz = DOT(w0, qvbz);
         const double S = sqrt((ubz * ubz) + (vbz * vbz));
         const double Kv = (lmix * lmix) * S;
@@ -1249,27 +1263,24 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
         X[2][c * CS + k] = Kv * vbz;
         if (k == 1) { s1[0][c] = ub; s1[1][c] = DOT(w0, qvb); }
     }
+    SX_STAMP(1);
     __syncthreads();
     if (k < MUBAR) {       // surface drag replaces the level-0 flux (src/shallowWaterModels.jl:463-482); lane k takes ring k
         const double Um = par[SX_P_UM], Vm = par[SX_P_VM];
-        {
-            const int mu = k;
-            const int c = mu * LAM + ll;
-            const double cs = cs_d, sn = sn_d;
-            const double sfcu = (Um * cs) + (Vm * sn), sfcv = (Vm * cs) - (Um * sn);
-            const double u10 = s1[0][c] + sfcu, v10 = s1[1][c] + sfcv;
-            const double U10 = sqrt(u10 * u10 + v10 * v10);
-            double Cd = par[SX_P_CD];
-            if (U10 < 5.2) Cd = 1.0e-3;
-            else if (U10 < 33.6) Cd = 4.4e-4 * sqrt(U10);
-            X[1][c * CS] = Cd * U10 * u10;
-            X[2][c * CS] = Cd * U10 * v10;
-        }
+        const int c = k * LAM + ll;
+        const double sfcu = (Um * cs_d) + (Vm * sn_d), sfcv = (Vm * cs_d) - (Um * sn_d);
+        const double u10 = s1[0][c] + sfcu, v10 = s1[1][c] + sfcv;
+        const double U10 = sqrt(u10 * u10 + v10 * v10);
+        double Cd = par[SX_P_CD];
+        if (U10 < 5.2) Cd = 1.0e-3;
+        else if (U10 < 33.6) Cd = 4.4e-4 * sqrt(U10);
+        X[1][c * CS] = Cd * U10 * u10;
+        X[2][c * CS] = Cd * U10 * v10;
     }
-    HIST(1)                // in flight during the column operators
     __syncthreads();
+    SX_STAMP(2);
     {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int wave = threadIdx.x >> 6;
         constexpr int RT = NZ / 16, NW = LAM * NZ / 64;
         constexpr int UPW = (RT * NT + NW - 1) / NW;         // (row tile, column tile) units per wave
         constexpr int KC = (NZ / 4 > 16) ? 8 : NZ / 4;       // operator fragments fetched per chunk (register budget)
@@ -1289,6 +1300,13 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
                         ai[ks] = a.MintT[ao + (int64_t)(kc + ks) * 4 * NZ];
                         ad[ks] = a.MdzT[ao + (int64_t)(kc + ks) * 4 * NZ];
                     }
+                    if (uu == 0 && kc == 0) {
+                        // ring 0's history goes out BEHIND the first operator fragments: the memory counter retires in issue
+                        // order, so fragments issued after it would wait for its HBM latency before the first MFMA
+                        SX_LOAD_FENCE();
+                        HIST(0)
+                        SX_LOAD_FENCE();
+                    }
 #pragma unroll
                     for (int ks = 0; ks < KC; ks++) {
                         c0[uu] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[ks], X[0][xo + (kc + ks) * 4], c0[uu], 0, 0, 0);
@@ -1298,6 +1316,8 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
                 }
             }
         }
+        if (RT * NT < NW && wave >= RT * NT) { HIST(0) }      // waves without a unit (never at the shipped shapes)
+        SX_STAMP(3);
         if (ALIAS) __syncthreads();
 #pragma unroll
         for (int uu = 0; uu < UPW; uu++) {
@@ -1312,13 +1332,19 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
         }
     }
     __syncthreads();
+    SX_STAMP(4);
+    HIST(1)
+    HIST(2)
+    SX_LOAD_FENCE();
+    NODE_TAKE(qh, rv[2]) NODE_TAKE(qhl, rd[3]) NODE_TAKE(qug, rv[3]) NODE_TAKE(qugl, rd[4]) NODE_TAKE(qvg, rv[4]) NODE_TAKE(qvgl, rd[5])
+    NODE_TAKE(qubl, rd[6]) NODE_TAKE(qubll, rd[7]) NODE_TAKE(qvbll, rd[8])
     double wb_keep = 0.0;
 #pragma unroll
     for (int mu = 0; mu < MUBAR; mu++) {
         const int64_t p = pc + mu * gs;
-        if (mu == 0) { HIST(2) }
-        const double *w0 = sphi[mu], *w1 = sphi[mu] + 4, *w2 = sphi[mu] + 8;
-        const double ri = srinv[mu], ri2 = ri * ri;
+        HIST_TAKE(mu)
+        const double *w0 = a.phiw[0][mu], *w1 = a.phiw[1][mu], *w2 = a.phiw[2][mu];
+        const double ri = rinv[mu], ri2 = ri * ri;
         const double h = DOT(w0, qh), hr = DOT(w1, qh), hl = DOT(w0, qhl);
         const double ug = DOT(w0, qug), ugr = DOT(w1, qug), ugl = DOT(w0, qugl);
         const double vg = DOT(w0, qvg), vgr = DOT(w1, qvg), vgl = DOT(w0, qvgl);
@@ -1361,9 +1387,14 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
         } else {
             __builtin_nontemporal_store(wb, a.np1 + (int64_t)5 * a.N + p);
         }
+        SX_STAMP(5 + mu);
     }
 #undef DOT
 #undef HIST
+#undef HIST_TAKE
+#undef NODE_V
+#undef NODE_D
+#undef NODE_TAKE
 }
 
 // semiimplicit_adjustment (src/semiimplicit.jl:521-597), one workgroup per group of columns
@@ -1426,6 +1457,29 @@ __global__ void __launch_bounds__(256) k_semiimplicit(SemiArgs a, int cpb) {
 
 // ------------------------------------------------------------------------------------------------ launchers
 static inline dim3 grid1(int64_t n, int bs) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+#ifdef SX_PHASES
+// diagnostic build: stamps of the LAST cell-kernel launch, written to $SX_PHASES_OUT (binary int64 [nwg][8]) by sx_destroy
+static long long *g_ph_buf = nullptr;
+static int64_t g_ph_n = 0;
+void phases_dump() {
+    const char *path = getenv("SX_PHASES_OUT");
+    if (!path || !g_ph_buf) return;
+    std::vector<long long> hst((size_t)g_ph_n * 8);
+    hipDeviceSynchronize();
+    hipMemcpy(hst.data(), g_ph_buf, sizeof(long long) * hst.size(), hipMemcpyDeviceToHost);
+    FILE *f = fopen(path, "wb");
+    if (f) { fwrite(hst.data(), sizeof(long long), hst.size(), f); fclose(f); }
+}
+static long long *phases_buffer(int64_t nwg) {
+    if (!g_ph_buf) {
+        hipMalloc(&g_ph_buf, sizeof(long long) * nwg * 8);
+        hipMemset(g_ph_buf, 0, sizeof(long long) * nwg * 8);
+        g_ph_n = nwg;
+    }
+    return nwg <= g_ph_n ? g_ph_buf : nullptr;
+}
+#endif
 
 void launch_zinv(sx_handle *h, bool full) {
     if (!h->has_z) return;
@@ -1493,6 +1547,7 @@ static PhysArgsT<ST> phys_args(sx_handle *h, int t) {
     a.ts = h->ts;
     for (int i = 0; i < SX_NPARAMS; i++) a.par[i] = h->par[i];
     a.col0 = 0; a.col1 = h->Nh; a.G = Planes<ST>{nullptr, nullptr}; a.phi = nullptr; a.NG = 0; a.L = 1; a.nrings = h->nrings;
+    a.dbg = nullptr;
     return a;
 }
 
@@ -1512,6 +1567,16 @@ static void launch_physics_t(sx_handle *h, int t, int part) {
         const int64_t split = (h->node_mode && h->node_active) ? (int64_t)h->R_in * h->uniform_L : h->Nh;
         if (h->d_G) a.G = planes_of<ST>(h->d_G, h->V, h->NG);
         a.phi = h->d_phi; a.NG = h->NG; a.L = h->uniform_L; a.nrings = h->nrings;
+        {
+            double phi[4][MUBAR][4];
+            basis_tables(h->DX, phi);
+            for (int d = 0; d < 3; d++)
+                for (int mu = 0; mu < MUBAR; mu++)
+                    for (int j = 0; j < 4; j++) a.phiw[d][mu][j] = phi[d][mu][j];
+            const double off3[MUBAR] = {-std::sqrt(3.0 / 5.0) / 2.0, 0.0, std::sqrt(3.0 / 5.0) / 2.0};     // as in sx_create
+            for (int mu = 0; mu < MUBAR; mu++) a.goff[mu] = off3[mu];
+            a.xmin = h->xmin; a.DX = h->DX; a.gcell0 = h->cell0;
+        }
         if (split > 0 && part != 2) {
             const int id = timer_id(h, split < h->Nh ? "k_phys_hrbl_inner" : "k_phys_hrbl");
             timer_begin(h, id);
@@ -1527,6 +1592,9 @@ static void launch_physics_t(sx_handle *h, int t, int part) {
             timer_begin(h, id);
             a.col0 = split; a.col1 = h->Nh;
             const int ncell = (h->nrings - h->R_in) / MUBAR;         // R_in is a multiple of 3 (sx_create)
+#ifdef SX_PHASES
+            a.dbg = phases_buffer((int64_t)ncell * (h->uniform_L / (h->nz == 64 ? 4 : h->nz == 32 ? 8 : 2)));
+#endif
 #define CELL_LAUNCH(NZ_, LAM_)                                                                                                     \
             do {                                                                                                                      \
                 if (h->wide) hipLaunchKernelGGL((k_phys_hrbl_cell<NZ_, LAM_, ST, true>), dim3(ncell * (h->uniform_L / LAM_)), dim3(LAM_ * NZ_), 0, h->stream, a, h->R_in / MUBAR);   \
