@@ -1,7 +1,8 @@
 #!/bin/bash
-# round-2 experiment driver (GPU box): microbenchmarks, GPU test suite, bench
+# round-2 experiment driver (GPU box): parity subset, A/B bench
 OUT=gpurun_out/r02; mkdir -p $OUT
-hipcc --offload-arch=gfx950 -O3 -o /tmp/pl profiles/micro/pipeline.hip && timeout -k 10 120 /tmp/pl > $OUT/pipeline.txt 2>&1
-cat $OUT/pipeline.txt
-timeout -k 10 900 python -m pytest tests -m gpu -q -s > $OUT/gpu_tests.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|FAILED|Error" $OUT/gpu_tests.log | tail -15
-timeout -k 10 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>$OUT/bench.err | tee $OUT/bench.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1), {k: round(x,4) for k,x in d['kernels_ms_per_step'].items()})"
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x -k "hrbl or node_space or fp32 or config4 or checkpoint or tiles_on_one" > $OUT/gpu_tests_subset.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/gpu_tests_subset.log
+for v in "SX_SBW_PF=0" "SX_SBW_PF=1" "SX_WIDE=0" "SX_WIDE=1"; do
+  env $v timeout -k 10 300 python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>$OUT/bench_ab.err | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value'],1), {k: round(x,4) for k,x in d['kernels_ms_per_step'].items()})" || exit 1
+done
+bash profiles/phases.sh

@@ -11,6 +11,8 @@
 //   forward: the workgroup first stages the [ring point][16 levels] tile through LDS with full 128-byte loads.
 #include "sx_internal.hpp"
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 namespace sx {
 
@@ -28,6 +30,14 @@ namespace sx {
 template <int LOGL> struct FftCfg {
     static constexpr int FZC = (LOGL <= 8) ? 16 : 8, FNP = FZC / 2, LOGZ = (LOGL <= 8) ? 4 : 3, SKEW = (LOGL <= 8) ? 2 : 0;
 };
+
+// phase stamps of the diagnostic build (-DSX_PHASES): [workgroup][8] cycle counts of the NODE inverse kernel, dumped by sx_destroy
+#ifdef SX_PHASES
+__device__ long long *g_fft_dbg = nullptr;
+#define FFT_STAMP(i) do { if (NODE && threadIdx.x == 0 && g_fft_dbg) g_fft_dbg[((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define FFT_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -147,6 +157,8 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
     constexpr int L = 1 << LOGL, T = L / 4;
     constexpr int FZC = FftCfg<LOGL>::FZC, FNP = FftCfg<LOGL>::FNP, LOGZ = FftCfg<LOGL>::LOGZ, SKEW = FftCfg<LOGL>::SKEW;
     extern __shared__ double2 smf[];
+    FFT_STAMP(0);
+    int nslot = 0;
     const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * FZC;
     const int zc = min(FZC, nz - z0);
     const int km = kmaxr[ring];
@@ -157,15 +169,19 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
     // two sets of FNP transform regions: slot i works in set i & 1, so the copy-out of slot i (global stores, never
     // waited for) overlaps the staging and transform of slot i + 1; one LDS-only workgroup barrier per slot
     int par = 0;
+    // twiddles and phase factors are fetched BEHIND the first group's coefficient loads (below): the memory counter retires
+    // in issue order, and the coefficients are what the first transform waits for.  (Phase stamps: a third of a
+    // workgroup's time used to pass before its first transform started - three dependent round trips.)
     Twiddles<LOGL> tw;
-    tw.template init<+1>(twg, t);
+    bool setup_done = false;
     const int j0 = NODE ? ring : ring / MUBAR;
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int mask = slotmask[v];
     const int k1 = t, k2 = t + T;                                  // this lane's two wavenumbers (k2 < L/2)
     const bool in1 = k1 <= km, in2 = k2 <= km;
-    const double2 ph1 = in1 ? phr[k1] : make_double2(1.0, 0.0), ph2 = in2 ? phr[k2] : make_double2(1.0, 0.0);
+    const int kc1 = min(k1, K2 / 2 - 1), kc2 = min(k2, K2 / 2 - 1);   // in-row addresses for lanes beyond the truncation (their values are dropped)
+    double2 ph1 = make_double2(1.0, 0.0), ph2 = ph1;               // node tables carry no phase offset
     const bool pair_ok = ((nz & 1) == 0);                          // (z, z+1) pairs are 16-byte aligned
 
     // groups of output slots that share one radial combination: (sz, d) = (0,0): u, l, ll; (0,1): r; (0,2): rr;
@@ -179,28 +195,41 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
         const bool n0 = sl0 >= 0 && ((mask >> sl0) & 1), n1 = sl1 >= 0 && ((mask >> sl1) & 1), n2 = sl2 >= 0 && ((mask >> sl2) & 1);
         if (!n0 && !n1 && !n2) continue;
         double2 a1 = make_double2(0.0, 0.0), b1 = a1, a2 = a1, b2 = a1;
-        if (active) {
+        {
+            constexpr int R = NODE ? 1 : 4;                // radial rows combined per coefficient
             const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
-            const double *a0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + za)) * K2;
-            const double *b0 = a0 + (hasb ? K2 : 0);
-#pragma unroll 2
-            for (int r = 0; r < (NODE ? 1 : 4); r++) {
+            const double *a0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + (active ? za : 0))) * K2;
+            const double *b0 = a0 + ((active && hasb) ? K2 : 0);
+            // every load of the group first (no branches: lanes beyond the truncation read a valid address and drop the value) ...
+            double2 x1[R], y1[R], x2[R], y2[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                x1[r] = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * kc1);
+                y1[r] = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * kc1);
+                x2[r] = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * kc2);
+                y2[r] = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * kc2);
+            }
+            if (!setup_done) {                             // ... then, once, the twiddles and phase factors behind them
+                asm volatile("" ::: "memory");
+                int tt = t;
+                asm volatile("" : "+v"(tt));               // opaque copy: the table addresses are formed HERE (hoisted out of the
+                                                           // group loop they were spilled, and every reload drained the memory counter)
+                tw.template init<+1>(twg, tt);
+                if (!NODE) { if (in1) ph1 = phr[tt]; if (in2) ph2 = phr[tt + T]; }
+                asm volatile("" ::: "memory");
+                setup_done = true;
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
                 const double fr = pf[r];
-                if (in1) {
-                    const double2 x = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * k1);
-                    const double2 y = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * k1);
-                    a1.x += fr * x.x; a1.y += fr * x.y; b1.x += fr * y.x; b1.y += fr * y.y;
-                }
-                if (in2) {
-                    const double2 x = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * k2);
-                    const double2 y = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * k2);
-                    a2.x += fr * x.x; a2.y += fr * x.y; b2.x += fr * y.x; b2.y += fr * y.y;
-                }
+                if (in1) { a1.x += fr * x1[r].x; a1.y += fr * x1[r].y; b1.x += fr * y1[r].x; b1.y += fr * y1[r].y; }
+                if (in2) { a2.x += fr * x2[r].x; a2.y += fr * x2[r].y; b2.x += fr * y2[r].x; b2.y += fr * y2[r].y; }
             }
             if (k1 == 0) { a1.y = 0.0; b1.y = 0.0; }      // block 0 is the real k = 0 coefficient, block 1 is padding
             if (!hasb) { b1 = make_double2(0.0, 0.0); b2 = b1; }
-            a1 = cmul(a1, ph1); b1 = cmul(b1, ph1); a2 = cmul(a2, ph2); b2 = cmul(b2, ph2);
+            if (!NODE) { a1 = cmul(a1, ph1); b1 = cmul(b1, ph1); a2 = cmul(a2, ph2); b2 = cmul(b2, ph2); }
         }
+        if (nslot == 0) FFT_STAMP(1);
         for (int ld = 0; ld < 3; ld++) {
             if (!(ld == 0 ? n0 : ld == 1 ? n1 : n2)) continue;
             const int slot = ld == 0 ? sl0 : ld == 1 ? sl1 : sl2;
@@ -228,7 +257,9 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
             if (COPYOUT) {
                 // last pass goes back to LDS, then the whole workgroup writes full 128-byte lines
                 fft_inplace<LOGL, +1, true>(X, tw, t, active);
+                if (nslot == 0) FFT_STAMP(2); else if (nslot == 1) FFT_STAMP(5);
                 lds_barrier();       // also orders the previous slot's copy-out reads (other set) before that set is restaged
+                if (nslot == 0) FFT_STAMP(3);
                 // thread -> (level pair zp, ring point l0 + (2 * 512 / FZC) i): a transform's LDS element l IS the pair of levels
                 // (2 zp, 2 zp + 1) of ring point l, so it leaves as one 16-byte store (8 bytes for fp32-stored slots);
                 // consecutive lanes cover the FZC levels of one point = one 128-byte line.  16 B per lane matters: at 8 B
@@ -257,6 +288,8 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                 };
                 if (slot == 0) copy_out(phys.val + (int64_t)v * N + p0 * nz + z0);
                 else copy_out(phys.der + ((int64_t)(slot - 1) * V + v) * N + p0 * nz + z0);
+                if (nslot == 0) FFT_STAMP(4); else if (nslot == 1) FFT_STAMP(6);
+                nslot++;
             } else {
                 const int64_t o0 = p0 * nz + z0 + za;
                 fft_inplace<LOGL, +1>(X, tw, t, active, [&](int l, double2 y) {
@@ -273,6 +306,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
             }
         }
     }
+    FFT_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -297,19 +331,34 @@ k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     const double *x = np1 + (int64_t)v * N + p0 * nz + z0;
     // stage the [ring point][FZC levels] tile: the (2 zp, 2 zp + 1) level pair of a point is one 16-byte load and one
     // LDS element of transform zp
-    if ((nz & 1) == 0) {
+    if ((nz & 1) == 0 && (int)blockDim.x == FNP * T) {
+        // the workgroup has FNP * L / 4 threads, the tile FNP * L pairs: exactly 4 per thread.  All four loads are issued before
+        // the first LDS write (rolled, every iteration was a load -> wait -> write round trip to HBM: four in a row)
         typedef double dv2 __attribute__((ext_vector_type(2)));
-        for (int o = tid; o < L * FNP; o += blockDim.x) {
-            const int zp = o & (FNP - 1), l = o >> (LOGZ - 1);
-            double2 val = make_double2(0.0, 0.0);
-            if (2 * zp + 1 < zc) {
-                const dv2 t2 = __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)l * nz + 2 * zp));
-                val = make_double2(t2.x, t2.y);
-            } else if (2 * zp < zc) {
-                val.x = __builtin_nontemporal_load(x + (int64_t)l * nz + 2 * zp);
+        const int zp = tid & (FNP - 1);
+        double2 val[4];
+        if (zc == FZC) {                                   // full chunk (wave-uniform): straight-line loads
+            dv2 t2[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                t2[i] = __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)((tid + i * FNP * T) >> (LOGZ - 1)) * nz + 2 * zp));
+#pragma unroll
+            for (int i = 0; i < 4; i++) val[i] = make_double2(t2[i].x, t2[i].y);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int l = (tid + i * FNP * T) >> (LOGZ - 1);
+                val[i] = make_double2(0.0, 0.0);
+                if (2 * zp + 1 < zc) {
+                    const dv2 t2 = __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)l * nz + 2 * zp));
+                    val[i] = make_double2(t2.x, t2.y);
+                } else if (2 * zp < zc) {
+                    val[i].x = __builtin_nontemporal_load(x + (int64_t)l * nz + 2 * zp);
+                }
             }
-            smf[zp * (L + SKEW) + l] = val;
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) smf[zp * (L + SKEW) + ((tid + i * FNP * T) >> (LOGZ - 1))] = val[i];
     } else {
         double *ba = (double *)smf;
         for (int o = tid; o < L * FZC; o += blockDim.x) {
@@ -414,9 +463,31 @@ void launch_rl_inverse_fft(sx_handle *h, const int *d_mask, int n_rings) {
 }
 
 // node-space inverse ("radial last", uniform rings): one transform set per radial node instead of per ring
+#ifdef SX_PHASES
+static long long *g_fft_buf = nullptr;
+static int64_t g_fft_n = 0;
+void fft_phases_dump() {
+    const char *path = getenv("SX_FFT_PHASES_OUT");
+    if (!path || !g_fft_buf) return;
+    std::vector<long long> hst((size_t)g_fft_n * 8);
+    hipDeviceSynchronize();
+    hipMemcpy(hst.data(), g_fft_buf, sizeof(long long) * hst.size(), hipMemcpyDeviceToHost);
+    FILE *f = fopen(path, "wb");
+    if (f) { fwrite(hst.data(), sizeof(long long), hst.size(), f); fclose(f); }
+}
+#endif
+
 void launch_node_fft(sx_handle *h) {
     const int id = timer_id(h, "k_node_fft");
     timer_begin(h, id);
+#ifdef SX_PHASES
+    if (!g_fft_buf) {
+        g_fft_n = (int64_t)((h->nz + fft_fzc(h->uniform_L) - 1) / fft_fzc(h->uniform_L)) * h->V * h->nbt;
+        hipMalloc(&g_fft_buf, sizeof(long long) * g_fft_n * 8);
+        hipMemset(g_fft_buf, 0, sizeof(long long) * g_fft_n * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_fft_dbg), &g_fft_buf, sizeof(g_fft_buf));
+    }
+#endif
     InvTarget tg{h->d_G, h->d_nphi, h->d_nkmax, h->d_npstart, h->d_nphoff, h->nbt, h->nbt, h->NG, 1};
     launch_inv_any(h, h->d_mask_node, tg);
     timer_end(h);

@@ -312,8 +312,8 @@ k_sbz(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
 // what bounds it).  Node c is complete once cell c has been added (cells c-3..c); its [NZ][64] tile then goes through
 // LDS into the vertical contraction with CB.  A segment starts 3 cells early to warm up its first nodes.
 // Summation order per node (cells ascending, mish points ascending) is the same as k_sbz's.
-template <int NZ>
-__global__ void __launch_bounds__(512)
+template <int NZ, bool PREFETCH>
+__global__ void __launch_bounds__(512, 2)       // second argument: waves per SIMD (one 512-thread workgroup per CU)
 k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__restrict__ phi, const double *__restrict__ wq,
       const double *__restrict__ CB, int ncells, int V, int Zb, int K2, int64_t C, int cps) {
     constexpr int ZPT = NZ / 8;
@@ -334,6 +334,21 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
     for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int i = 0; i < ZPT; i++) acc[q][i] = 0.0;
+    // The ring spectra of cell c + 1 are requested as soon as cell c has been accumulated, BEFORE its node is contracted: the
+    // loads then fly during the LDS contraction instead of starting after it (a workgroup used to have at most ~11 loads
+    // per wave in flight and none at all during the contraction; read once: non-temporal, the caches stay with B and the
+    // history).
+    double xn[PREFETCH ? MUBAR : 1][ZPT];
+    auto fetch = [&](int c) {
+        if (!PREFETCH || c < cstart || c >= cend || c >= ncells) return;
+#pragma unroll
+        for (int mu = 0; mu < MUBAR; mu++) {
+            const double *src = base + (int64_t)(c * MUBAR + mu) * plane;
+#pragma unroll
+            for (int i = 0; i < ZPT; i++) xn[mu][i] = __builtin_nontemporal_load(src + (int64_t)(8 * i) * K2);
+        }
+    };
+    fetch(cstart);
     for (int c4 = cstart & ~3; c4 < cend; c4 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -346,10 +361,15 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
                     const double w = wq[ring];
                     const double w0 = w * phi[(int64_t)ring * 4], w1 = w * phi[(int64_t)ring * 4 + 1];
                     const double w2 = w * phi[(int64_t)ring * 4 + 2], w3 = w * phi[(int64_t)ring * 4 + 3];
-                    const double *src = base + (int64_t)ring * plane;
                     double x[ZPT];
+                    if (PREFETCH) {
 #pragma unroll
-                    for (int i = 0; i < ZPT; i++) x[i] = __builtin_nontemporal_load(src + (int64_t)(8 * i) * K2);   // read once (1.3x with the warm-up cells): keep the caches for B and the history
+                        for (int i = 0; i < ZPT; i++) x[i] = xn[mu][i];
+                    } else {
+                        const double *src = base + (int64_t)ring * plane;
+#pragma unroll
+                        for (int i = 0; i < ZPT; i++) x[i] = __builtin_nontemporal_load(src + (int64_t)(8 * i) * K2);
+                    }
 #pragma unroll
                     for (int i = 0; i < ZPT; i++) {
                         acc[u][i] += w0 * x[i];
@@ -358,6 +378,7 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
                         acc[(u + 3) & 3][i] += w3 * x[i];
                     }
                 }
+                fetch(c + 1);           // in flight while node c goes through LDS and the vertical contraction
             }
             if (c >= ca) {                      // node c is complete: vertical forward transform and store
                 __syncthreads();                // the previous node's tile has been consumed
@@ -974,131 +995,6 @@ __global__ void __launch_bounds__(256) k_phys_hrbl(PhysArgsT<ST> a, int cpb) {
 // (L2-resident) operator, B and the result tiles live in LDS, column-major with a 2-double pad (bank-conflict free).
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-// CPB columns per workgroup (<= 16, the MFMA tile width).  Used for the rings on the ring-wise path (all of them without
-// the node-space inverse, the inner ones with it; k_phys_hrbl_cell takes the rest).
-template <int NZ, int CPB, class ST>
-__global__ void __launch_bounds__(CPB * NZ) k_phys_hrbl_mfma(PhysArgsT<ST> a) {
-    constexpr int CS = NZ + 2;                     // column stride in LDS
-    __shared__ double X[3][16 * CS];               // div, Kv*ubz, Kv*vbz   -> inputs (columns >= CPB unused)
-    // wb, d/dz(...), d/dz(...) -> outputs.  At zDim = 128 the two tile sets would exceed the 64 KB of static LDS: the results
-    // then wait in the accumulators until every wave has finished reading X and are written over it.
-    constexpr bool ALIAS = (NZ > 64);
-    __shared__ double Ysep[ALIAS ? 1 : 3][ALIAS ? 1 : 16 * CS];
-    double (*Y)[16 * CS] = ALIAS ? X : reinterpret_cast<double (*)[16 * CS]>(&Ysep[0][0]);
-    __shared__ double s1[2][16];                   // ub, vb at level 1 ("10 m")
-    const int k = threadIdx.x % NZ, cl = threadIdx.x / NZ;
-    const int64_t col = a.col0 + (int64_t)blockIdx.x * CPB + cl;
-    const bool live = col < a.col1;
-    const double *par = a.par;
-    const double g = par[SX_P_G], Kh = par[SX_P_KH], Hfree = par[SX_P_HFREE], f = par[SX_P_F];
-    const int64_t p = live ? col * NZ + k : 0;
-    double r = 1.0, h = 0, hr = 0, hl = 0, ug = 0, ugr = 0, ugl = 0, vg = 0, vgr = 0, vgl = 0;
-    double ub = 0, ubr = 0, ubrr = 0, ubl = 0, ubll = 0, ubz = 0, vb = 0, vbr = 0, vbrr = 0, vbl = 0, vbll = 0, vbz = 0;
-    double xd = 0.0, xu = 0.0, xv = 0.0;
-    // 22 divisions by r / r^2 per point would make this kernel VALU-bound (an f64 division is ~25 instructions): the
-    // reciprocal is formed once per thread and multiplied (differs from the reference's a / r by <= 1.5 ulp)
-    double ri = 1.0, ri2 = 1.0;
-    // tendency history of the five prognostic variables: fetched now so that its HBM latency overlaps the load phase
-    // (with one 1024-thread workgroup per CU nothing else would hide it at the end of the kernel)
-    double e1h[5] = {0, 0, 0, 0, 0}, e2h[5] = {0, 0, 0, 0, 0};
-    double cs_d = 0.0, sn_d = 0.0;      // cos / sin(lambda) of the surface-drag lane, fetched with everything else
-    if (live && k == 0) { cs_d = a.cosl[col]; sn_d = a.sinl[col]; }
-    if (live) {
-#pragma unroll
-        for (int v = 0; v < 5; v++) {
-            if (a.t >= 2) e1h[v] = __builtin_nontemporal_load(a.E1 + (int64_t)v * a.N + p);
-            if (a.t >= 3) e2h[v] = __builtin_nontemporal_load(a.E2 + (int64_t)v * a.N + p);
-        }
-        r = a.r[col];
-        ri = 1.0 / r;
-        ri2 = ri * ri;
-        h = PSV(0); hr = PS(0, a.s_r); hl = PS(0, a.s_l);
-        ug = PSV(1); ugr = PS(1, a.s_r); ugl = PS(1, a.s_l);
-        vg = PSV(2); vgr = PS(2, a.s_r); vgl = PS(2, a.s_l);
-        ub = PSV(3); ubr = PS(3, a.s_r); ubrr = PS(3, a.s_rr); ubl = PS(3, a.s_l); ubll = PS(3, a.s_ll); ubz = PS(3, a.s_z);
-        vb = PSV(4); vbr = PS(4, a.s_r); vbrr = PS(4, a.s_rr); vbl = PS(4, a.s_l); vbll = PS(4, a.s_ll); vbz = PS(4, a.s_z);
-        const double S = sqrt((ubz * ubz) + (vbz * vbz));
-        const double l = 1.0 / ((1.0 / (0.4 * a.z[k])) + (1.0 / 80.0));
-        const double Kv = (l * l) * S;
-        xd = -((ub * ri) + ubr + (vbl * ri));
-        xu = Kv * ubz;
-        xv = Kv * vbz;
-        if (k == 1) { s1[0][cl] = ub; s1[1][cl] = vb; }
-    }
-    __syncthreads();
-    if (live && k == 0) {
-        const double Um = par[SX_P_UM], Vm = par[SX_P_VM];
-        const double cs = cs_d, sn = sn_d;
-        const double sfcu = (Um * cs) + (Vm * sn), sfcv = (Vm * cs) - (Um * sn);
-        const double u10 = s1[0][cl] + sfcu, v10 = s1[1][cl] + sfcv;
-        const double U10 = sqrt(u10 * u10 + v10 * v10);
-        double Cd = par[SX_P_CD];
-        if (U10 < 5.2) Cd = 1.0e-3;
-        else if (U10 < 33.6) Cd = 4.4e-4 * sqrt(U10);
-        xu = Cd * U10 * u10;
-        xv = Cd * U10 * v10;
-    }
-    X[0][cl * CS + k] = xd;
-    X[1][cl * CS + k] = xu;
-    X[2][cl * CS + k] = xv;
-    __syncthreads();
-    {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        constexpr int RT = NZ / 16;                 // row tiles per operand
-        constexpr int NW = CPB * NZ / 64;           // waves in the workgroup
-        constexpr int JPW = (3 * RT + NW - 1) / NW;  // jobs per wave
-        mfma_d4 acc[JPW];
-#pragma unroll
-        for (int jj = 0; jj < JPW; jj++) {
-            const int job = wave + jj * NW;
-            acc[jj] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-            if (job < 3 * RT) {
-                const int op = job / RT, rt = job % RT;
-                const double *MT = (op == 0) ? a.MintT : a.MdzT;      // MT[j][k] = M[k][j]
-                const double *xb = X[op] + (lane & 15) * CS + (lane >> 4);
-                const double *ma = MT + (int64_t)(lane >> 4) * NZ + rt * 16 + (lane & 15);
-#pragma unroll 4
-                for (int ks = 0; ks < NZ / 4; ks++)
-                    acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[(int64_t)ks * 4 * NZ], xb[ks * 4], acc[jj], 0, 0, 0);
-            }
-        }
-        if (ALIAS) __syncthreads();
-#pragma unroll
-        for (int jj = 0; jj < JPW; jj++) {
-            const int job = wave + jj * NW;
-            if (job < 3 * RT) {
-                const int op = job / RT, rt = job % RT;
-                double *yo = Y[op] + (lane & 15) * CS + rt * 16 + (lane >> 4);
-                yo[0] = acc[jj][0]; yo[4] = acc[jj][1]; yo[8] = acc[jj][2]; yo[12] = acc[jj][3];
-            }
-        }
-    }
-    __syncthreads();
-    if (!live) return;
-    const double wb = Y[0][cl * CS + k], vdu = Y[1][cl * CS + k], vdv = Y[2][cl * CS + k];
-    if (a.write_w) a.P.val[(int64_t)5 * a.N + p] = wb;
-    const double e0 = ((-vg * hl * ri) + (-ug * hr)) + (-(Hfree + h) * ((ug * ri) + ugr + (vgl * ri)));
-    const double e1 = ((-vg * ugl * ri) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg * ri)));
-    const double e2 = ((-vg * vgl * ri) + (-ug * vgr)) + (-g * (hl * ri)) + (-ug * (f + (vg * ri)));
-    const double e3 = ((-vb * ubl * ri) + (-ub * ubr) + (-wb * ubz)) + (-g * hr) + (vb * (f + (vb * ri))) + vdu +
-                      (Kh * ((ubr * ri) + ubrr - (ub * ri2) + (ubll * ri2) - (2.0 * vbl * ri2)));
-    const double e4 = ((-vb * vbl * ri) + (-ub * vbr) + (-wb * vbz)) + (-g * (hl * ri)) + (-ub * (f + (vb * ri))) + vdv +
-                      (Kh * ((vbr * ri) + vbrr - (vb * ri2) + (vbll * ri2) + (2.0 * ubl * ri2)));
-    const double uu[5] = {h, ug, vg, ub, vb}, ee[5] = {e0, e1, e2, e3, e4};
-#pragma unroll
-    for (int v = 0; v < 5; v++) {          // explicit_timestep (src/semiimplicit.jl:672-698) with the prefetched history
-        const int64_t o = (int64_t)v * a.N + p;
-        __builtin_nontemporal_store(ee[v], a.En + o);
-        double un;
-        if (a.t == 1) un = uu[v] + (a.ts * ee[v]);
-        else if (a.t == 2) un = uu[v] + (0.5 * a.ts) * ((3.0 * ee[v]) - e1h[v]);
-        else un = uu[v] + ((a.ts / 12.0) * ((23.0 * ee[v]) - (16.0 * e1h[v]) + (5.0 * e2h[v])));
-        __builtin_nontemporal_store(un, a.np1 + o);
-    }
-    __builtin_nontemporal_store(wb, a.np1 + (int64_t)5 * a.N + p);
-    for (int v = 6; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
-}
-
 // 16 bytes per lane for streams that are 8 bytes per point.  A wave owns 64 consecutive doubles of every stream; lanes
 // 0-31 fetch TWO consecutive elements of stream a, lanes 32-63 of stream b (one global_load_dwordx4 instead of two
 // dwordx2), and one v_permlane32_swap per dword leaves (a[e], b[e]) in every lane with e = 2 (lane & 31) + (lane >> 5) -
@@ -1149,6 +1045,195 @@ __device__ __forceinline__ void store_pair_nt(double *pa, double *pb, int lane, 
 // keeps the loads in front of it in front of the loads behind it (the memory counter retires in issue order: what is
 // needed first must be issued first)
 #define SX_LOAD_FENCE() asm volatile("" ::: "memory")
+
+// CPB columns per workgroup (<= 16, the MFMA tile width).  Used for the rings on the ring-wise path (all of them without
+// the node-space inverse, the inner ones with it; k_phys_hrbl_cell takes the rest).
+// Load discipline as in k_phys_hrbl_cell: one burst at entry, oldest = needed first (the memory counter retires in issue
+// order); the tendency history and the second half of the planes are consumed only after the column operators; all operator
+// fragments of a wave's jobs are requested before its first MFMA.  WIDE: 16-byte-per-lane pairs (issue_pair / take_pair).
+template <int NZ, int CPB, class ST, bool WIDE>
+__global__ void __launch_bounds__(CPB * NZ, 4) k_phys_hrbl_mfma(PhysArgsT<ST> a) {      // 4 waves per SIMD: <= 128 VGPRs, two 512-thread workgroups per CU
+    constexpr int CS = NZ + 2;                     // column stride in LDS
+    __shared__ double X[3][16 * CS];               // div, Kv*ubz, Kv*vbz   -> inputs (columns >= CPB unused)
+    // wb, d/dz(...), d/dz(...) -> outputs.  At zDim = 128 the two tile sets would exceed the 64 KB of static LDS: the results
+    // then wait in the accumulators until every wave has finished reading X and are written over it.
+    constexpr bool ALIAS = (NZ > 64);
+    __shared__ double Ysep[ALIAS ? 1 : 3][ALIAS ? 1 : 16 * CS];
+    double (*Y)[16 * CS] = ALIAS ? X : reinterpret_cast<double (*)[16 * CS]>(&Ysep[0][0]);
+    __shared__ double s1[2][16];                   // ub, vb at level 1 ("10 m")
+    const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+    const int elem = WIDE ? wbase + wide_elem(lane) : (int)threadIdx.x;      // element of the workgroup's CPB x NZ block
+    const int k = elem % NZ, cl = elem / NZ;
+    const int64_t col = a.col0 + (int64_t)blockIdx.x * CPB + cl;
+    const bool live = col < a.col1;
+    const double *par = a.par;
+    const double g = par[SX_P_G], Kh = par[SX_P_KH], Hfree = par[SX_P_HFREE], f = par[SX_P_F];
+    const int64_t p = live ? col * NZ + k : 0;
+    // this lane's PAIR (elements 2i, 2i + 1 of the wave's 64: same column as its own element since NZ is even)
+    const int64_t pw = live ? (a.col0 + (int64_t)blockIdx.x * CPB) * NZ + wbase + 2 * (lane & 31) : 0;
+    typedef typename Vec2<ST>::type SV;
+    double xd = 0.0, xu = 0.0, xv = 0.0;
+    // ---- the burst.  Small per-column values first (they come back first), then the planes the column operators need,
+    // then the rest.
+    double r = 1.0, zk = 1.0, cs_d = 0.0, sn_d = 0.0;
+    if (live) { r = a.r[col]; zk = a.z[k]; }
+    if (live && k == 0) { cs_d = a.cosl[col]; sn_d = a.sinl[col]; }
+    // planes as (value-type) v0: ub | v1: vb | v2: h | v3: ug | v4: vg and (derivative-type) pairs
+    double ub = 0, vb = 0, h = 0, ug = 0, vg = 0;
+    double ubr = 0, vbl = 0, ubz = 0, vbz = 0, hr = 0, hl = 0, ugr = 0, ugl = 0, vgr = 0, vgl = 0, ubrr = 0, ubl = 0, ubll = 0, vbr = 0, vbrr = 0, vbll = 0;
+    dbl2v rv0, rv1;              // (ub, vb), (h, ug); vg travels alone
+    SV rd[8];                    // (ubr, vbl) (ubz, vbz) | (hr, hl) (ugr, ugl) (vgr, vgl) (ubrr, ubl) (ubll, vbr) (vbrr, vbll)
+#define PV(v) (a.P.val + (int64_t)(v) * a.N)
+#define PD(v, s) (a.P.der + ((int64_t)((s) - 1) * a.V + (v)) * a.N)
+#define LD2V(raw, x, y, va, vb_) { if (WIDE) raw = issue_pair<false>(PV(va) + pw, PV(vb_) + pw, lane); else { x = PV(va)[p]; y = PV(vb_)[p]; } }
+#define LD2D(raw, x, y, va, sa, vb_, sb) { if (WIDE) raw = issue_pair<false>(PD(va, sa) + pw, PD(vb_, sb) + pw, lane); else { x = (double)PD(va, sa)[p]; y = (double)PD(vb_, sb)[p]; } }
+    if (live) {
+        LD2V(rv0, ub, vb, 3, 4)
+        LD2D(rd[0], ubr, vbl, 3, a.s_r, 4, a.s_l)
+        LD2D(rd[1], ubz, vbz, 3, a.s_z, 4, a.s_z)
+        SX_LOAD_FENCE();
+        LD2V(rv1, h, ug, 0, 1)
+        vg = PV(2)[p];
+        LD2D(rd[2], hr, hl, 0, a.s_r, 0, a.s_l)
+        LD2D(rd[3], ugr, ugl, 1, a.s_r, 1, a.s_l)
+        LD2D(rd[4], vgr, vgl, 2, a.s_r, 2, a.s_l)
+        LD2D(rd[5], ubrr, ubl, 3, a.s_rr, 3, a.s_l)
+        LD2D(rd[6], ubll, vbr, 3, a.s_ll, 4, a.s_r)
+        LD2D(rd[7], vbrr, vbll, 4, a.s_rr, 4, a.s_ll)
+        SX_LOAD_FENCE();
+    }
+    // tendency history of the five prognostic variables: requested behind the operator fragments (below)
+    double e1h[5] = {0, 0, 0, 0, 0}, e2h[5] = {0, 0, 0, 0, 0};
+    dbl2v rh[5];
+    // 22 divisions by r / r^2 per point would make this kernel VALU-bound (an f64 division is ~25 instructions): the
+    // reciprocal is formed once per thread and multiplied (differs from the reference's a / r by <= 1.5 ulp)
+    double ri = 1.0, ri2 = 1.0;
+    if (live) {
+        if (WIDE) { take_pair(rv0, ub, vb); take_pair(rd[0], ubr, vbl); take_pair(rd[1], ubz, vbz); }
+        ri = 1.0 / r;
+        ri2 = ri * ri;
+        const double S = sqrt((ubz * ubz) + (vbz * vbz));
+        const double l = 1.0 / ((1.0 / (0.4 * zk)) + (1.0 / 80.0));
+        const double Kv = (l * l) * S;
+        xd = -((ub * ri) + ubr + (vbl * ri));
+        xu = Kv * ubz;
+        xv = Kv * vbz;
+        if (k == 1) { s1[0][cl] = ub; s1[1][cl] = vb; }
+    }
+    __syncthreads();
+    if (live && k == 0) {
+        const double Um = par[SX_P_UM], Vm = par[SX_P_VM];
+        const double cs = cs_d, sn = sn_d;
+        const double sfcu = (Um * cs) + (Vm * sn), sfcv = (Vm * cs) - (Um * sn);
+        const double u10 = s1[0][cl] + sfcu, v10 = s1[1][cl] + sfcv;
+        const double U10 = sqrt(u10 * u10 + v10 * v10);
+        double Cd = par[SX_P_CD];
+        if (U10 < 5.2) Cd = 1.0e-3;
+        else if (U10 < 33.6) Cd = 4.4e-4 * sqrt(U10);
+        xu = Cd * U10 * u10;
+        xv = Cd * U10 * v10;
+    }
+    X[0][cl * CS + k] = xd;
+    X[1][cl * CS + k] = xu;
+    X[2][cl * CS + k] = xv;
+    __syncthreads();
+    {
+        const int wave = threadIdx.x >> 6;
+        constexpr int RT = NZ / 16;                 // row tiles per operand
+        constexpr int NW = CPB * NZ / 64;           // waves in the workgroup
+        constexpr int JPW = (3 * RT + NW - 1) / NW;  // jobs per wave
+        constexpr int KS = NZ / 4;                  // MFMA steps per job
+        constexpr int KC = 8;                       // operator fragments requested at a time (register budget: 128 VGPRs)
+        mfma_d4 acc[JPW];
+#pragma unroll
+        for (int jj = 0; jj < JPW; jj++) {
+            const int job = wave + jj * NW;
+            acc[jj] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+            const bool has = job < 3 * RT;
+            const int op = has ? job / RT : 0, rt = has ? job % RT : 0;
+            const double *MT = (op == 0) ? a.MintT : a.MdzT;      // MT[j][k] = M[k][j]
+            const double *xb = X[op] + (lane & 15) * CS + (lane >> 4);
+            const double *ma = MT + (int64_t)(lane >> 4) * NZ + rt * 16 + (lane & 15);
+            for (int kc = 0; kc < KS; kc += KC) {
+                double af[KC];
+#pragma unroll
+                for (int ks = 0; ks < KC; ks++) af[ks] = has ? ma[(int64_t)(kc + ks) * 4 * NZ] : 0.0;
+                if (jj == 0 && kc == 0) {
+                    // the history goes out BEHIND the first operator fragments: fragments issued after it would wait for its
+                    // HBM latency before the first MFMA
+                    SX_LOAD_FENCE();
+                    if (live) {
+#pragma unroll
+                        for (int v = 0; v < 5; v++) {
+                            if (WIDE) {
+                                if (a.t >= 2) rh[v] = issue_pair<true>(a.E1 + (int64_t)v * a.N + pw, a.E2 + (int64_t)v * a.N + pw, lane);
+                            } else {
+                                if (a.t >= 2) e1h[v] = __builtin_nontemporal_load(a.E1 + (int64_t)v * a.N + p);
+                                if (a.t >= 3) e2h[v] = __builtin_nontemporal_load(a.E2 + (int64_t)v * a.N + p);
+                            }
+                        }
+                    }
+                    SX_LOAD_FENCE();
+                }
+                if (has) {
+#pragma unroll
+                    for (int ks = 0; ks < KC; ks++)
+                        acc[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[ks], xb[(kc + ks) * 4], acc[jj], 0, 0, 0);
+                }
+            }
+        }
+        if (ALIAS) __syncthreads();
+#pragma unroll
+        for (int jj = 0; jj < JPW; jj++) {
+            const int job = wave + jj * NW;
+            if (job < 3 * RT) {
+                const int op = job / RT, rt = job % RT;
+                double *yo = Y[op] + (lane & 15) * CS + rt * 16 + (lane >> 4);
+                yo[0] = acc[jj][0]; yo[4] = acc[jj][1]; yo[8] = acc[jj][2]; yo[12] = acc[jj][3];
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    if (WIDE) {
+        take_pair(rv1, h, ug);
+        take_pair(rd[2], hr, hl); take_pair(rd[3], ugr, ugl); take_pair(rd[4], vgr, vgl);
+        take_pair(rd[5], ubrr, ubl); take_pair(rd[6], ubll, vbr); take_pair(rd[7], vbrr, vbll);
+#pragma unroll
+        for (int v = 0; v < 5; v++)
+            if (a.t >= 2) { take_pair(rh[v], e1h[v], e2h[v]); if (a.t < 3) e2h[v] = 0.0; }
+    }
+    const double wb = Y[0][cl * CS + k], vdu = Y[1][cl * CS + k], vdv = Y[2][cl * CS + k];
+    if (a.write_w) a.P.val[(int64_t)5 * a.N + p] = wb;
+    const double e0 = ((-vg * hl * ri) + (-ug * hr)) + (-(Hfree + h) * ((ug * ri) + ugr + (vgl * ri)));
+    const double e1 = ((-vg * ugl * ri) + (-ug * ugr)) + (-g * hr) + (vg * (f + (vg * ri)));
+    const double e2 = ((-vg * vgl * ri) + (-ug * vgr)) + (-g * (hl * ri)) + (-ug * (f + (vg * ri)));
+    const double e3 = ((-vb * ubl * ri) + (-ub * ubr) + (-wb * ubz)) + (-g * hr) + (vb * (f + (vb * ri))) + vdu +
+                      (Kh * ((ubr * ri) + ubrr - (ub * ri2) + (ubll * ri2) - (2.0 * vbl * ri2)));
+    const double e4 = ((-vb * vbl * ri) + (-ub * vbr) + (-wb * vbz)) + (-g * (hl * ri)) + (-ub * (f + (vb * ri))) + vdv +
+                      (Kh * ((vbr * ri) + vbrr - (vb * ri2) + (vbll * ri2) + (2.0 * ubl * ri2)));
+    const double uu[5] = {h, ug, vg, ub, vb}, ee[5] = {e0, e1, e2, e3, e4};
+#pragma unroll
+    for (int v = 0; v < 5; v++) {          // explicit_timestep (src/semiimplicit.jl:672-698) with the prefetched history
+        const int64_t o = (int64_t)v * a.N + p;
+        double un;
+        if (a.t == 1) un = uu[v] + (a.ts * ee[v]);
+        else if (a.t == 2) un = uu[v] + (0.5 * a.ts) * ((3.0 * ee[v]) - e1h[v]);
+        else un = uu[v] + ((a.ts / 12.0) * ((23.0 * ee[v]) - (16.0 * e1h[v]) + (5.0 * e2h[v])));
+        if (WIDE) {
+            store_pair_nt(a.En + (int64_t)v * a.N + pw, a.np1 + (int64_t)v * a.N + pw, lane, ee[v], un);
+        } else {
+            __builtin_nontemporal_store(ee[v], a.En + o);
+            __builtin_nontemporal_store(un, a.np1 + o);
+        }
+    }
+    __builtin_nontemporal_store(wb, a.np1 + (int64_t)5 * a.N + p);
+    for (int v = 6; v < a.V; v++) ab_step(a, v, p, PSV(v), 0.0);
+#undef PV
+#undef PD
+#undef LD2V
+#undef LD2D
+}
 
 // Cell-wise node-space variant ("radial last", uniform rings): one workgroup = LAM azimuths x NZ levels of ONE radial
 // cell, i.e. the 3 rings that share the same 4 spline nodes.  Each thread loads the 14 node transforms of its
@@ -1581,9 +1666,15 @@ static void launch_physics_t(sx_handle *h, int t, int part) {
             const int id = timer_id(h, split < h->Nh ? "k_phys_hrbl_inner" : "k_phys_hrbl");
             timer_begin(h, id);
             a.col0 = 0; a.col1 = split;
-            if (h->nz == 64) hipLaunchKernelGGL((k_phys_hrbl_mfma<64, PCPB, ST>), grid1(split, PCPB), dim3(PCPB * 64), 0, h->stream, a);
-            else if (h->nz == 32) hipLaunchKernelGGL((k_phys_hrbl_mfma<32, PCPB, ST>), grid1(split, PCPB), dim3(PCPB * 32), 0, h->stream, a);
-            else hipLaunchKernelGGL((k_phys_hrbl_mfma<128, 8, ST>), grid1(split, 8), dim3(8 * 128), 0, h->stream, a);
+#define RING_LAUNCH(NZ_, CPB_)                                                                                                     \
+            do {                                                                                                                      \
+                if (h->wide) hipLaunchKernelGGL((k_phys_hrbl_mfma<NZ_, CPB_, ST, true>), grid1(split, CPB_), dim3(CPB_ * NZ_), 0, h->stream, a);   \
+                else hipLaunchKernelGGL((k_phys_hrbl_mfma<NZ_, CPB_, ST, false>), grid1(split, CPB_), dim3(CPB_ * NZ_), 0, h->stream, a);          \
+            } while (0)
+            if (h->nz == 64) RING_LAUNCH(64, PCPB);
+            else if (h->nz == 32) RING_LAUNCH(32, PCPB);
+            else RING_LAUNCH(128, 8);
+#undef RING_LAUNCH
             HIPCHK(hipGetLastError());
             timer_end(h);
         }
@@ -1700,16 +1791,18 @@ void launch_sb(sx_handle *h) {
         const int id = timer_id(h, "k_sbz");
         timer_begin(h, id);
         if (h->nz == 64 || h->nz == 32 || h->nz == 128) {
-            // cells per workgroup (+3 warm-up cells): about 1.5 workgroups per CU (one round of 2 resident workgroups; 11 at
-            // config 4, measured best of 4..12), on large tiles never fewer than 6 so that the warm-up stays below half of the reads
+            // cells per workgroup (+3 warm-up cells).  With the prefetch (zDim <= 64: 177 VGPRs, one 512-thread workgroup per
+            // CU) the grid is ONE round of at most 256 workgroups; without it (zDim 128: 16 values per thread and ring leave no
+            // registers for a second set; or SX_SBW_PF=0) about 1.5 workgroups per CU as before.  On large tiles never fewer
+            // than 6 cells so that the warm-up stays below half of the reads
             const int groups = ((h->K2 + 63) / 64) * h->V;
-            // zDim 128 runs one 512-thread workgroup per CU (229 VGPRs): one full round of 256 instead of 1.5 rounds of 2 x 256
-            const int nseg = std::max(1, (h->nz == 128 ? 256 : 384) / groups);
+            const bool pf = h->sbw_prefetch && h->nz <= 64;
+            const int nseg = std::max(1, (pf || h->nz == 128 ? 256 : 384) / groups);
             // small tiles (multi-GPU strong scaling): the kernel is then one workgroup's latency chain, which is proportional
             // to the cells it walks, so short segments (down to 2 cells + 3 warm-up) beat the saved re-reads
             const int cps = std::max(h->ncells <= 64 ? 2 : 6, (h->ncells + nseg - 1) / nseg);
             dim3 gw((h->K2 + 63) / 64, h->V, (h->ncells + cps - 1) / cps);
-            auto kern = h->nz == 64 ? k_sbw<64> : h->nz == 32 ? k_sbw<32> : k_sbw<128>;
+            auto kern = h->nz == 64 ? (pf ? k_sbw<64, true> : k_sbw<64, false>) : h->nz == 32 ? (pf ? k_sbw<32, true> : k_sbw<32, false>) : k_sbw<128, false>;
             hipLaunchKernelGGL(kern, gw, dim3(512), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->d_CB, h->ncells,
                                h->V, h->Zb, h->K2, h->C, cps);
             HIPCHK(hipGetLastError());
