@@ -135,6 +135,8 @@ def main():
                     help="N > 1: 'lib' = ncclSend/Recv/AllGather issued inside libscythe_hip.so on the tile's stream (sx_exchange), "
                          "'torch' = torch.distributed collectives on device tensors (always used with --backend gloo)")
     ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip the 2-step comparison of the two exchange implementations")
+    ap.add_argument("--no-native", action="store_true", help="skip the native-ragged-ring run reported as native_equivalent")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="diagnostic: no hipEvent pair per kernel in the timed loop (no roofline object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=0, help="0 = time the C port on the full grid (default); n > 0 = extrapolate from n cells")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -206,20 +208,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Warm-up, with every kernel timed (rank 0): finds the dominant kernel and gives the per-kernel table.  An event pair
+    # costs ~8 us on the stream, 16 pairs per step were 6 % of the step - so the TIMED region below carries the pair of the
+    # dominant kernel only (the roofline object needs that one, measured live over the timed region).
+    use_timers = (rank == 0 and not args.no_kernel_timers)
+    tile.enable_timers(use_timers)
+    tile.reset_timers()
     for _ in range(args.warmup):
         run.step()
     barrier()
-    # per-kernel hipEvent timers feed the roofline object, which only rank 0 prints: the other ranks skip the two event
-    # records per launch (at N = 8 a step is ~10 launches of ~30 us each, so the records are not free)
-    tile.enable_timers(rank == 0)
+    warm = tile.timers() if use_timers else {}
+    all_kernels = {k: v[0] / max(args.warmup, 1) for k, v in warm.items()}
+    dominant = max(warm.items(), key=lambda kv: kv[1][0])[0] if warm and args.warmup > 0 else None
+    tile.timer_only(dominant)
     tile.reset_timers()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run.step()
     barrier()
     elapsed = time.perf_counter() - t0
-    timers = tile.timers()
+    timers = {k: v for k, v in tile.timers().items() if v[1] > 0}
     tile.enable_timers(False)
+    tile.timer_only(None)
     nan = tile.check_nan()
 
     if dist is not None:
@@ -230,9 +240,11 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         # dominant kernel by accumulated device time
+        if not timers:                      # --no-kernel-timers (diagnostic)
+            timers = {"none": (0.0, 0)}
         name, (ms, calls) = max(timers.items(), key=lambda kv: kv[1][0])
         avg_ms = ms / max(calls, 1)
-        bytes_per_launch = tile.kernel_bytes(name)
+        bytes_per_launch = tile.kernel_bytes(name) if calls else 0.0
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         nc, _, nz = WORKLOADS[args.workload]
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE,
@@ -245,7 +257,7 @@ def main():
             pmc = json.load(open(tfile))
             if pmc.get("_meta", {}).get("lib_sha256") == hashlib.sha256(open(S.LIB_PATH, "rb").read()).hexdigest():
                 traffic = pmc.get(name, {}).get("hbm_bytes")
-                step_traffic = sum(pmc[k]["hbm_bytes"] * (timers[k][1] / args.steps) for k in timers if k in pmc)
+                step_traffic = sum(pmc[k]["hbm_bytes"] * (warm[k][1] / max(args.warmup, 1)) for k in warm if k in pmc)
         out = {
             "metric": ("model steps/sec, RLZ 512x256x64 shallow-water" if args.workload == "rlz_513x256x64"
                        else "model steps/sec, %s shallow-water (not the headline configuration)" % args.workload),
@@ -273,8 +285,36 @@ def main():
                          "step_traffic": step_traffic,
                          "step_achieved": (step_traffic / (ms_per_step * 1e-3) / 1e9) if step_traffic else None,
                          "step_frac": (step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic else None},
-            "kernels_ms_per_step": {k: v[0] / args.steps for k, v in sorted(timers.items())},
+            # every kernel, from the warm-up steps (all event pairs on); the dominant one again from the timed region
+            "kernels_ms_per_step": {k: v for k, v in sorted(all_kernels.items())},
+            "dominant_kernel_ms_timed_region": {k: v[0] / args.steps for k, v in sorted(timers.items())},
         }
+        if world == 1 and args.workload == "rlz_513x256x64" and not args.no_native:
+            # The same model on Springsteel's NATIVE ragged rings (SURVEY.md 8(d) "native-equivalent shape": 85 cells -> 255 rings
+            # of 4 + 4 ri points, 131,580 horizontal points x 64 levels): the layout a drop-in must run, timed in the same process
+            # after the headline loop.  Its azimuthal transforms are dense truncated DFTs on the f64 matrix cores (sx_dft.hip).
+            try:
+                kwn, _ = grid_kwargs(args.workload)
+                kwn["num_cells"] = 85
+                gpn = S.GridParameters(ring_uniform_L=0, storage=args.storage, **kwn)
+                mpn = S.ModelParameters(ts=TS, equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gpn, physical_params=dict(PAR))
+                runn = S.ModelRun(mpn, num_tiles=1, device=dev)
+                runn.set_initial_conditions([initial_condition(S.getGridpoints(runn.tiles[0]))])
+                for _ in range(3):
+                    runn.step()
+                torch.cuda.synchronize()
+                nsteps = max(5, min(args.steps, 30))
+                t1 = time.perf_counter()
+                for _ in range(nsteps):
+                    runn.step()
+                torch.cuda.synchronize()
+                dtn = (time.perf_counter() - t1) / nsteps
+                out["native_equivalent"] = {"steps_per_s": 1.0 / dtn, "ms_per_step": 1e3 * dtn, "steps": nsteps, "nan": bool(runn.tiles[0].check_nan()),
+                                            "workload": "RLZ 85 cells -> 255 native ragged rings (4 + 4 ri points, kmax = ri), %d points x 6 vars"
+                                                        % runn.tiles[0].N}
+                runn.close()
+            except Exception as e:
+                out["native_equivalent"] = {"steps_per_s": None, "error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_cells, args.cpu_steps)

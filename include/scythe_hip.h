@@ -259,6 +259,9 @@ int sx_exchange(sx_handle *h);
 /* hipEvent timers around every kernel on the handle's stream (off by default). */
 int sx_enable_timers(sx_handle *h, int32_t on);
 int sx_reset_timers(sx_handle *h);
+/* restrict the event pairs to the kernel with this timer name (NULL = every kernel): two event records per launch cost
+ * ~4 us each on the stream, so a timed region that only needs its dominant kernel's duration should not pay for all */
+int sx_timer_only(sx_handle *h, const char *name);
 /* names[i] borrowed static strings; ms[i] accumulated milliseconds; calls[i] launches. Returns count via n. */
 int sx_get_timers(sx_handle *h, int32_t max, const char **names, double *ms, int64_t *calls, int32_t *n);
 /* algorithmic bytes of one launch of the named kernel (SURVEY.md 8(d) accounting), 0 if unknown */

@@ -89,6 +89,7 @@ SYMBOLS = {
     "sx_exchange": (C.c_int, [_H]),
     "sx_enable_timers": (C.c_int, [_H, C.c_int32]),
     "sx_reset_timers": (C.c_int, [_H]),
+    "sx_timer_only": (C.c_int, [_H, C.c_char_p]),
     "sx_get_timers": (C.c_int, [_H, C.c_int32, C.POINTER(C.c_char_p), P_D, P_I64, P_I32]),
     "sx_kernel_bytes": (C.c_int, [_H, C.c_char_p, P_D]),
 }

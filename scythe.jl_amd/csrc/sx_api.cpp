@@ -93,7 +93,9 @@ static hipEvent_t get_event(sx_handle *h) {
 }
 
 void timer_begin(sx_handle *h, int id) {
+    h->timer_skip = false;
     if (!h->timers_on) return;
+    if (!h->timer_only.empty() && h->timer_only != h->timers[id].name) { h->timer_skip = true; return; }
     if (h->pending.size() >= 8192) timers_flush(h);
     PendingEvent p;
     p.timer = id;
@@ -104,7 +106,7 @@ void timer_begin(sx_handle *h, int id) {
 }
 
 void timer_end(sx_handle *h) {
-    if (!h->timers_on || h->pending.empty()) return;
+    if (!h->timers_on || h->timer_skip || h->pending.empty()) return;
     hipEventRecord(h->pending.back().b, h->stream);
 }
 
@@ -1044,6 +1046,13 @@ int sx_enable_timers(sx_handle *h, int32_t on) {
     if (!h) { set_error("null handle"); return 1; }
     if (!on) timers_flush(h);
     h->timers_on = on;
+    return 0;
+}
+
+int sx_timer_only(sx_handle *h, const char *name) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    h->timer_only = name ? name : "";
     return 0;
 }
 

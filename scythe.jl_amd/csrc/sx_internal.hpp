@@ -152,6 +152,8 @@ struct sx_handle {
     std::vector<void *> allocs;
     // timers
     int timers_on = 0;
+    bool timer_skip = false;          // the launch in progress is not timed (sx_timer_only)
+    std::string timer_only;           // when set, only this kernel gets its event pair
     std::vector<sx::Timer> timers;
     std::vector<sx::PendingEvent> pending;
     std::vector<hipEvent_t> event_pool;

@@ -413,6 +413,10 @@ class Grid:
     def enable_timers(self, on=True):
         L.check(self._lib.sx_enable_timers(self._h, int(on)))
 
+    def timer_only(self, name=None):
+        """Time only the kernel with this timer name (None: all)."""
+        L.check(self._lib.sx_timer_only(self._h, name.encode() if name else None))
+
     def reset_timers(self):
         L.check(self._lib.sx_reset_timers(self._h))
 

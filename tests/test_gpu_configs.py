@@ -81,12 +81,12 @@ def test_config3_rz_513x128_semiimplicit_three_way():
     assert three["HIP vs LU oracle"][1] <= 2.0 * three["LU oracle vs extended"][1] + 1e-12
 
 
-def _bench_model(num_tiles, exchange="a2a", split="reference"):
+def _bench_model(num_tiles, exchange="a2a", split="reference", workload="rlz_513x256x64", storage="f64"):
     import bench
     import scythe_jl_amd as S
-    kw, L = bench.grid_kwargs("rlz_513x256x64")
-    gp = S.GridParameters(ring_uniform_L=L, **kw)
-    mp = S.ModelParameters(ts=bench.TS, equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
+    kw, L = bench.grid_kwargs(workload)
+    gp = S.GridParameters(ring_uniform_L=L, storage=storage, **kw)
+    mp = S.ModelParameters(ts=bench.TS_OF.get(workload, bench.TS), equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
                            physical_params=dict(bench.PAR))
     run = S.ModelRun(mp, num_tiles=num_tiles, device="cuda", exchange=exchange, split=split)
     run.set_initial_conditions([bench.initial_condition(S.getGridpoints(g)) for g in run.tiles])
@@ -169,4 +169,94 @@ def test_config4_full_size_azimuthal_derivative_slots_are_the_spectral_derivativ
                 scale = max(np.abs(u).max(), 1e-300)
                 assert np.abs(phys[idx, v, 3] - dl).max() <= 1e-9 * max(np.abs(dl).max(), scale)
                 assert np.abs(phys[idx, v, 4] - dll).max() <= 1e-8 * max(np.abs(dll).max(), scale)
+    run.close()
+
+
+# ----------------------------------------------------------------------------- config 5 at its workload
+# RLZ 1023 x 512 x 128 (341 cells), fp32-stored derivative planes: the two-wave 512-point FFT with a full spectrum
+# (kmax 255), the 128-level cell-wise and ring-wise equation-set kernels and the 128-level sliding-window inner products at
+# full size.  The oracle cannot step 67 M points; these are the size-independent properties of the config-4 tests, plus (in
+# test_gpu_parity.py) an oracle comparison at 90 cells x 512-point rings where every FFT bin carries signal.
+C5 = "rlz_1023x512x128"
+
+
+def _np1_fields(run):
+    out = []
+    for g in run.tiles:
+        assert not g.check_nan()
+        out.append(g.var_np1)
+    return np.concatenate(out, axis=0)
+
+
+def _max_rel(a, b):
+    return max(np.abs(a[:, v] - b[:, v]).max() / max(np.abs(b[:, v]).max(), 1e-300) for v in range(a.shape[1]))
+
+
+def test_config5_full_size_f32_storage_finite_and_close_to_f64_storage():
+    """20 steps at full size: no NaN, and the fp32-stored-derivative run stays within the declared fp32-mode tolerance
+    (1e-6 of each variable's scale, tests/test_gpu_parity.py) of the all-fp64 run of the same library."""
+    a = _bench_model(1, workload=C5, storage="f32")
+    assert a.tiles[0].N == 1023 * 512 * 128
+    b = _bench_model(1, workload=C5, storage="f64")
+    for _ in range(20):
+        a.step()
+        b.step()
+    fa, fb = _np1_fields(a), _np1_fields(b)
+    err = _max_rel(fa, fb)
+    print("\nconfig 5 full size, 20 steps: fp32-stored derivative planes vs all-fp64, max relative field difference %.2e" % err)
+    assert 0.0 < err < 1e-6, err
+    a.close()
+    b.close()
+
+
+def test_config5_full_size_node_space_equals_ring_wise_and_tiling_invariance(monkeypatch):
+    """fp32 storage at full size: (1) the node-space inverse + cell-wise kernel against the ring-wise kernels everywhere
+    (SX_NODE_MODE=0); (2) two radial tiles (transposed solve) against one tile."""
+    one = _bench_model(1, workload=C5, storage="f32")
+    two = _bench_model(2, workload=C5, storage="f32")
+    for _ in range(3):
+        one.step()
+        two.step()
+    f1, f2 = _np1_fields(one), _np1_fields(two)
+    e_tiles = _max_rel(f2, f1)
+    two.close()
+    del f2
+    monkeypatch.setenv("SX_NODE_MODE", "0")
+    ring = _bench_model(1, workload=C5, storage="f32")
+    for _ in range(3):
+        ring.step()
+    e_ring = _max_rel(_np1_fields(ring), f1)
+    print("\nconfig 5 full size, 3 steps (fp32-stored derivative planes): 2 tiles vs 1 tile %.2e; ring-wise vs node-space %.2e" % (e_tiles, e_ring))
+    # the state path is fp64 in both arrangements; tiles change only the summation order of B (rounding), the two inverse
+    # paths round their fp32-stored derivative planes at different places (ring values vs node values): fp32-mode tolerance
+    assert e_tiles < 1e-11, e_tiles
+    assert e_ring < 1e-6, e_ring
+    one.close()
+    ring.close()
+
+
+def test_config5_full_size_azimuthal_derivative_slots_are_the_spectral_derivatives():
+    """tileTransform! at full size with fp32-stored derivative planes: on sampled rings / levels the d/dlambda and d2/dlambda2
+    slots equal the FFT derivatives (numpy) of the fp64 value slot to fp32 rounding of the slot (512-point rings, kmax 255)."""
+    run = _bench_model(1, workload=C5, storage="f32")
+    g = run.tiles[0]
+    g.tileTransform_()
+    phys = g.physical
+    L, nz = 512, 128
+    k = np.fft.rfftfreq(L, 1.0 / L)
+    worst = 0.0
+    for ring in (0, 9, 300, 766, 1022):
+        for z in (0, 64, 127):
+            for v in (0, 2, 4):
+                idx = (ring * L + np.arange(L)) * nz + z
+                u = phys[idx, v, 0]
+                spec = np.fft.rfft(u)
+                dl = np.fft.irfft(1j * k * spec, L)
+                dll = np.fft.irfft(-(k ** 2) * spec, L)
+                scale = max(np.abs(u).max(), 1e-300)
+                e1 = np.abs(phys[idx, v, 3] - dl).max() / max(np.abs(dl).max(), scale)
+                e2 = np.abs(phys[idx, v, 4] - dll).max() / max(np.abs(dll).max(), scale)
+                worst = max(worst, e1, e2)
+    print("\nconfig 5 full size: lambda-derivative slots vs numpy FFT derivative of the value slot, worst %.2e (fp32 storage: 6e-8)" % worst)
+    assert worst < 5e-7, worst
     run.close()

@@ -191,6 +191,24 @@ def test_fp32_storage_mode_within_declared_tolerance(maker, kw):
     assert 1e-9 < err_all < F32_TOL_DER, err_all      # the lower bound proves the fp32 path really ran
 
 
+def test_fp32_storage_512_point_rings_every_wavenumber_against_the_oracle():
+    """Config 5's transform shape where the oracle still steps in seconds: 90 cells x 512-point rings (kmax reaches 255, so
+    every bin of the two-wave 512-point FFT carries signal) x 16 levels, fp32-stored derivative planes, 3 steps against the
+    fp64 oracle at the declared fp32-mode tolerance."""
+    case = cases.rlz_hrbl(num_cells=90, zDim=16, ring_L=512)
+    ref = cases.OracleModel(case)
+    hip = cases.HipModel(case, storage="f32")
+    for _ in range(3):
+        ref.step()
+        hip.step()
+    a, b = hip.physical(), ref.physical()
+    err_val = cases.rel_err_per_var(a[:, :, :1], b[:, :, :1])
+    err_all = cases.per_slot_errors(a, b)
+    print("\nfp32-stored derivative planes, 270 rings x 512 x 16, 3 steps: values %.2e, slots %s" % (err_val, " ".join("%.1e" % e for e in err_all)))
+    assert err_val < F32_TOL_VAL, err_val
+    assert 1e-9 < err_all.max() < F32_TOL_DER, err_all
+
+
 @pytest.mark.parametrize("maker,kw,ntiles", [(cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}, 1),
                                              (cases.rz_semiimplicit, {}, 1),
                                              (cases.rl_slab, {"num_cells": 9}, 3)])
