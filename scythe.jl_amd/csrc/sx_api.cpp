@@ -263,6 +263,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->overlap = getenv("SX_OVERLAP") && atoi(getenv("SX_OVERLAP")) != 0;
     h->wide = !(getenv("SX_WIDE") && atoi(getenv("SX_WIDE")) == 0);
     h->sbw_prefetch = getenv("SX_SBW_PF") && atoi(getenv("SX_SBW_PF")) != 0;
+    h->sbw_mfma = !(getenv("SX_SBW_MFMA") && atoi(getenv("SX_SBW_MFMA")) == 0);
     h->cell0 = g->tile_cell0; h->ncells = g->tile_num_cells; h->tile_num = g->tile_num;
     h->nrings = MUBAR * h->ncells; h->nbt = h->ncells + 3;
     for (int i = 0; i < 7; i++) h->slot[i] = DERIV_SLOTS[h->geom][i];
@@ -588,6 +589,7 @@ int sx_destroy(sx_handle *h) {
 #ifdef SX_PHASES
     phases_dump();
     fft_phases_dump();
+    sbw_phases_dump();
 #endif
     comm_release(h);
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }

@@ -111,6 +111,7 @@ struct sx_handle {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 0;
+    int sbw_mfma = 1;       // k_sbw_mfma (matrix-core vertical contraction, operator in registers) for zDim 64 / 32 (SX_SBW_MFMA=0: k_sbw)
     int sbw_prefetch = 0;   // k_sbw requests the next cell's ring spectra before contracting the current node (SX_SBW_PF=0: off)
     int wide = 1;    // 16-byte-per-lane loads / stores in the equation-set kernels (SX_WIDE=0: the 8-byte forms, A/B timing)
     std::vector<int> hmask_full, hmask_eq;       // host copies of d_mask_full / d_mask_eq
@@ -191,5 +192,6 @@ void comm_release(sx_handle *h);
 #ifdef SX_PHASES
 void phases_dump();
 void fft_phases_dump();
+void sbw_phases_dump();
 #endif
 }  // namespace sx

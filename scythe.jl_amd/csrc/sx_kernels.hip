@@ -312,6 +312,18 @@ k_sbz(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
 // what bounds it).  Node c is complete once cell c has been added (cells c-3..c); its [NZ][64] tile then goes through
 // LDS into the vertical contraction with CB.  A segment starts 3 cells early to warm up its first nodes.
 // Summation order per node (cells ascending, mish points ascending) is the same as k_sbz's.
+#ifdef SX_PHASES
+__device__ long long *g_sbw_dbg = nullptr;     // [workgroup][8]: cycles in load+accumulate, barrier 1, LDS write + barrier 2, contraction + stores; cells; total
+#define SBW_T0() long long st_ = (long long)__builtin_readcyclecounter(); const long long st0_ = st_; long long sacc_[4] = {0, 0, 0, 0}; int scells_ = 0
+#define SBW_LAP(i) do { const long long n_ = (long long)__builtin_readcyclecounter(); sacc_[i] += n_ - st_; st_ = n_; } while (0)
+#define SBW_END() do { if (threadIdx.x == 0 && g_sbw_dbg) { long long *d_ = g_sbw_dbg + ((int64_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8; \
+        d_[0] = sacc_[0]; d_[1] = sacc_[1]; d_[2] = sacc_[2]; d_[3] = sacc_[3]; d_[4] = scells_; d_[5] = (long long)__builtin_readcyclecounter() - st0_; } } while (0)
+#else
+#define SBW_T0() do { } while (0)
+#define SBW_LAP(i) do { } while (0)
+#define SBW_END() do { } while (0)
+#endif
+
 template <int NZ, bool PREFETCH>
 __global__ void __launch_bounds__(512, 2)       // second argument: waves per SIMD (one 512-thread workgroup per CU)
 k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__restrict__ phi, const double *__restrict__ wq,
@@ -349,11 +361,15 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
         }
     };
     fetch(cstart);
+    SBW_T0();
     for (int c4 = cstart & ~3; c4 < cend; c4 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int c = c4 + u;
             if (c < cstart || c >= cend) continue;
+#ifdef SX_PHASES
+            scells_++;
+#endif
             if (c < ncells) {
 #pragma unroll
                 for (int mu = 0; mu < MUBAR; mu++) {
@@ -380,11 +396,14 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
                 }
                 fetch(c + 1);           // in flight while node c goes through LDS and the vertical contraction
             }
+            SBW_LAP(0);
             if (c >= ca) {                      // node c is complete: vertical forward transform and store
                 __syncthreads();                // the previous node's tile has been consumed
+                SBW_LAP(1);
 #pragma unroll
                 for (int i = 0; i < ZPT; i++) As[(g + 8 * i) * 64 + lane] = acc[u][i];
                 __syncthreads();
+                SBW_LAP(2);
                 double *dst = dst0 + (int64_t)c * C;
                 for (int o0 = g * 4; o0 < Zb; o0 += 32) {
                     const double *m0 = CB + (int64_t)o0 * NZ;
@@ -407,11 +426,129 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
                         if (o0 + 3 < Zb) dst[(int64_t)(o0 + 3) * K2] = a3;
                     }
                 }
+                SBW_LAP(3);
             }
 #pragma unroll
             for (int i = 0; i < ZPT; i++) acc[u][i] = 0.0;      // the slot now belongs to node c + 4
         }
     }
+    SBW_END();
+}
+
+// The same with the vertical contraction on the f64 matrix cores and the next cell's ring spectra in flight meanwhile
+// (zDim 64 / 32; b_zDim <= 64).  Phase stamps of k_sbw (profiles/r02/phases_sbw.txt): 57 % of a workgroup's time was the
+// contraction - 11,000 cycles per node against ~1,500 of arithmetic: its operator entries arrive as scalar loads, two
+// dependent batches per 8 terms, and with 43 output rows over 8 waves x 4 rows three waves ran a second pass while five
+// waited.  Here the operator lives in LDS in MFMA-fragment order for the whole kernel: wave w owns column tile w & 3 (16 wavenumber blocks)
+// and the row tiles of its half (w < 4: the first ceil(MT / 2) tiles of 16 modes, else the rest), 16 K-steps of
+// v_mfma_f64_16x16x4_f64 per tile with B = the node's [level][block] tile in LDS (row stride 80 doubles: the 4 levels a
+// K-step reads fall in disjoint bank halves).  One 512-thread workgroup per CU; the grid is one round.
+// Summation order differs from k_sbw / k_sbz (K in blocks of 4): results agree to rounding, not bitwise.
+template <int NZ>
+__global__ void __launch_bounds__(512, 2)
+k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *__restrict__ phi, const double *__restrict__ wq,
+           const double *__restrict__ CB, int ncells, int V, int Zb, int K2, int64_t C, int cps) {
+    constexpr int ZPT = NZ / 8, KS = NZ / 4, LS = 80;
+    __shared__ double As[NZ * LS];
+    const int lane = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * 64 + lane;
+    const int v = blockIdx.y;
+    const bool ok = blk < K2;
+    const int ca = blockIdx.z * cps, cb = min(ca + cps, ncells);
+    const int cend = (cb == ncells) ? ncells + 3 : cb;          // the last segment also owns the 3 trailing nodes
+    const int cstart = max(0, ca - 3);
+    const int64_t plane = (int64_t)V * NZ * K2;
+    const double *base = Fl + ((int64_t)v * NZ + g) * K2 + (ok ? blk : 0);
+    // operator fragments: A[m][k] = CB[m][k], lane supplies m = 16 mt + (lane & 15), k = 4 js + (lane >> 4)
+    const int MT = (Zb + 15) / 16, mhalf = (MT + 1) / 2;
+    const int mt0 = g < 4 ? 0 : mhalf, nmt = g < 4 ? mhalf : MT - mhalf;      // this wave's row tiles [mt0, mt0 + nmt), nmt <= 2
+    const int nt = g & 3, n = lane & 15, kk = lane >> 4;
+    // (kept in LDS in fragment order [row tile][K step][lane]: a conflict-free 8-byte read per MFMA; in registers the two
+    // tiles' 64 VGPRs pushed the kernel into spills)
+    __shared__ double Af[4 * KS * 64];
+    for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
+        const int l = e & 63, js = (e >> 6) % KS, mt = e / (64 * KS);
+        const int m = mt * 16 + (l & 15);
+        Af[e] = (m < Zb) ? CB[(int64_t)m * NZ + 4 * js + (l >> 4)] : 0.0;
+    }
+    const double *af0 = Af + (size_t)mt0 * KS * 64 + lane, *af1 = af0 + (nmt > 1 ? KS * 64 : 0);
+    double acc[4][ZPT];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+#pragma unroll
+        for (int i = 0; i < ZPT; i++) acc[q][i] = 0.0;
+    double xn[MUBAR][ZPT];
+    auto fetch = [&](int c) {
+        if (c < cstart || c >= cend || c >= ncells) return;
+#pragma unroll
+        for (int mu = 0; mu < MUBAR; mu++) {
+            const double *src = base + (int64_t)(c * MUBAR + mu) * plane;
+#pragma unroll
+            for (int i = 0; i < ZPT; i++) xn[mu][i] = __builtin_nontemporal_load(src + (int64_t)(8 * i) * K2);
+        }
+    };
+    fetch(cstart);
+    SBW_T0();
+    for (int c4 = cstart & ~3; c4 < cend; c4 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = c4 + u;
+            if (c < cstart || c >= cend) continue;
+#ifdef SX_PHASES
+            scells_++;
+#endif
+            if (c < ncells) {
+#pragma unroll
+                for (int mu = 0; mu < MUBAR; mu++) {
+                    const int ring = c * MUBAR + mu;
+                    const double w = wq[ring];
+                    const double w0 = w * phi[(int64_t)ring * 4], w1 = w * phi[(int64_t)ring * 4 + 1];
+                    const double w2 = w * phi[(int64_t)ring * 4 + 2], w3 = w * phi[(int64_t)ring * 4 + 3];
+#pragma unroll
+                    for (int i = 0; i < ZPT; i++) {
+                        acc[u][i] += w0 * xn[mu][i];
+                        acc[(u + 1) & 3][i] += w1 * xn[mu][i];
+                        acc[(u + 2) & 3][i] += w2 * xn[mu][i];
+                        acc[(u + 3) & 3][i] += w3 * xn[mu][i];
+                    }
+                }
+                fetch(c + 1);           // in flight while node c goes through LDS and the matrix cores
+            }
+            SBW_LAP(0);
+            if (c >= ca) {                      // node c is complete: vertical forward transform and store
+                __syncthreads();                // the previous node's tile has been consumed
+                SBW_LAP(1);
+#pragma unroll
+                for (int i = 0; i < ZPT; i++) As[(g + 8 * i) * LS + lane] = acc[u][i];
+                __syncthreads();
+                SBW_LAP(2);
+                colmat_d4 o0 = {0.0, 0.0, 0.0, 0.0}, o1 = o0;
+                const double *xb = As + kk * LS + nt * 16 + n;
+#pragma unroll
+                for (int js = 0; js < KS; js++) {
+                    const double b = xb[(4 * js) * LS];
+                    o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[js * 64], b, o0, 0, 0, 0);
+                    if (nmt > 1) o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[js * 64], b, o1, 0, 0, 0);
+                }
+                // D[row = kk + 4 r][col = n]
+                const int col = blockIdx.x * 64 + nt * 16 + n;
+                if (col < K2) {
+                    double *dst = B + (int64_t)c * C + (int64_t)v * Zb * K2 + col;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int m0 = mt0 * 16 + kk + 4 * r, m1 = m0 + 16;
+                        if (nmt > 0 && m0 < Zb) dst[(int64_t)m0 * K2] = o0[r];
+                        if (nmt > 1 && m1 < Zb) dst[(int64_t)m1 * K2] = o1[r];
+                    }
+                }
+                SBW_LAP(3);
+            }
+#pragma unroll
+            for (int i = 0; i < ZPT; i++) acc[u][i] = 0.0;      // the slot now belongs to node c + 4
+        }
+    }
+    SBW_END();
 }
 
 // ------------------------------------------------------------------------------------------------ B -> A banded SPD solve
@@ -1556,6 +1693,17 @@ void phases_dump() {
     FILE *f = fopen(path, "wb");
     if (f) { fwrite(hst.data(), sizeof(long long), hst.size(), f); fclose(f); }
 }
+static long long *g_sbw_buf = nullptr;
+static int64_t g_sbw_n = 0;
+void sbw_phases_dump() {
+    const char *path = getenv("SX_SBW_PHASES_OUT");
+    if (!path || !g_sbw_buf) return;
+    std::vector<long long> hst((size_t)g_sbw_n * 8);
+    hipDeviceSynchronize();
+    hipMemcpy(hst.data(), g_sbw_buf, sizeof(long long) * hst.size(), hipMemcpyDeviceToHost);
+    FILE *f = fopen(path, "wb");
+    if (f) { fwrite(hst.data(), sizeof(long long), hst.size(), f); fclose(f); }
+}
 static long long *phases_buffer(int64_t nwg) {
     if (!g_ph_buf) {
         hipMalloc(&g_ph_buf, sizeof(long long) * nwg * 8);
@@ -1796,13 +1944,23 @@ void launch_sb(sx_handle *h) {
             // registers for a second set; or SX_SBW_PF=0) about 1.5 workgroups per CU as before.  On large tiles never fewer
             // than 6 cells so that the warm-up stays below half of the reads
             const int groups = ((h->K2 + 63) / 64) * h->V;
-            const bool pf = h->sbw_prefetch && h->nz <= 64;
+            const bool mf = h->sbw_mfma && h->nz <= 64 && h->Zb <= 64;      // matrix-core contraction + prefetch (k_sbw_mfma)
+            const bool pf = (h->sbw_prefetch && h->nz <= 64) || mf;
             const int nseg = std::max(1, (pf || h->nz == 128 ? 256 : 384) / groups);
             // small tiles (multi-GPU strong scaling): the kernel is then one workgroup's latency chain, which is proportional
             // to the cells it walks, so short segments (down to 2 cells + 3 warm-up) beat the saved re-reads
             const int cps = std::max(h->ncells <= 64 ? 2 : 6, (h->ncells + nseg - 1) / nseg);
             dim3 gw((h->K2 + 63) / 64, h->V, (h->ncells + cps - 1) / cps);
+#ifdef SX_PHASES
+            if (!g_sbw_buf) {
+                g_sbw_n = (int64_t)gw.x * gw.y * gw.z;
+                hipMalloc(&g_sbw_buf, sizeof(long long) * g_sbw_n * 8);
+                hipMemset(g_sbw_buf, 0, sizeof(long long) * g_sbw_n * 8);
+                hipMemcpyToSymbol(HIP_SYMBOL(g_sbw_dbg), &g_sbw_buf, sizeof(g_sbw_buf));
+            }
+#endif
             auto kern = h->nz == 64 ? (pf ? k_sbw<64, true> : k_sbw<64, false>) : h->nz == 32 ? (pf ? k_sbw<32, true> : k_sbw<32, false>) : k_sbw<128, false>;
+            if (mf) kern = h->nz == 64 ? k_sbw_mfma<64> : k_sbw_mfma<32>;
             hipLaunchKernelGGL(kern, gw, dim3(512), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->d_CB, h->ncells,
                                h->V, h->Zb, h->K2, h->C, cps);
             HIPCHK(hipGetLastError());
