@@ -180,11 +180,19 @@ def main():
         return r
 
     if world > 1 and impl == "lib":
+        run, err = None, ""
         try:
             run = make_run("lib")
-        except Exception as e:          # RCCL could not be bound / initialised inside the library: say so, use torch's
-            print("bench.py: in-library exchange unavailable (%r), using torch.distributed" % (e,), file=sys.stderr)
-            impl = "torch (lib failed: %s)" % (str(e)[:120],)
+        except Exception as e:          # RCCL could not be bound / initialised inside the library
+            err = str(e)[:120]
+        # every rank must take the same path: agree on the outcome before anybody moves on
+        okf = torch.tensor([1 if run is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        if int(okf.item()) == 0:
+            print("bench.py: in-library exchange unavailable on some rank (%s), using torch.distributed" % err, file=sys.stderr)
+            if run is not None:
+                run.close()
+            impl = "torch (lib failed: %s)" % err
             run = make_run("torch")
         if impl == "lib" and not args.no_selfcheck:
             # both implementations of the exchange, two steps each from the same initial condition: same fields

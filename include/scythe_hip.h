@@ -254,6 +254,11 @@ int sx_comm_init(sx_handle *h, int32_t n_tiles, int32_t my_tile, const int32_t *
 int sx_comm_attach(sx_handle *h, int32_t n_tiles, int32_t my_tile, const int32_t *tile_cell0, const int32_t *tile_num_cells,
                    int32_t mode, void *nccl_comm);
 int sx_exchange(sx_handle *h);
+/* The same exchange with all n tiles in ONE process on one GPU (handles hs[0..n-1] = tiles 0..n-1): identical buffer geometry
+ * and offset tables, every send / receive pair replaced by a device-to-device copy.  For single-GPU multi-tile runs and for
+ * testing the exchange without RCCL (which refuses two ranks on one device). */
+int sx_comm_init_local(sx_handle **hs, int32_t n_tiles, const int32_t *tile_cell0, const int32_t *tile_num_cells, int32_t mode);
+int sx_exchange_local(sx_handle **hs, int32_t n_tiles);
 
 /* --- measurement ---------------------------------------------------------------------------------------------------- */
 /* hipEvent timers around every kernel on the handle's stream (off by default). */

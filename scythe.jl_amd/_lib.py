@@ -87,6 +87,8 @@ SYMBOLS = {
     "sx_comm_init": (C.c_int, [_H, C.c_int32, C.c_int32, P_I32, P_I32, C.c_int32, C.c_char_p]),
     "sx_comm_attach": (C.c_int, [_H, C.c_int32, C.c_int32, P_I32, P_I32, C.c_int32, C.c_void_p]),
     "sx_exchange": (C.c_int, [_H]),
+    "sx_comm_init_local": (C.c_int, [C.POINTER(_H), C.c_int32, P_I32, P_I32, C.c_int32]),
+    "sx_exchange_local": (C.c_int, [C.POINTER(_H), C.c_int32]),
     "sx_enable_timers": (C.c_int, [_H, C.c_int32]),
     "sx_reset_timers": (C.c_int, [_H]),
     "sx_timer_only": (C.c_int, [_H, C.c_char_p]),

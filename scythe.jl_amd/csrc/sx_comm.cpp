@@ -165,6 +165,70 @@ int sx_comm_attach(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, co
     return 0;
 }
 
+// Loopback transport: all n tiles live in this process on one GPU.  The same buffer geometry and offsets as the RCCL path,
+// with every (send, recv) pair replaced by a device-to-device copy on the receiving tile's stream - so the offset tables of
+// sx_exchange are exercised by the single-GPU test suite for n = 2, 3, 4 tiles (RCCL itself refuses two ranks on one device).
+int sx_comm_init_local(sx_handle **hs, int32_t n, const int32_t *cell0, const int32_t *ncells, int32_t mode) {
+    clear_error();
+    if (!hs || !cell0 || !ncells || n < 1) { set_error("sx_comm_init_local: invalid argument"); return 1; }
+    for (int t = 0; t < n; t++) {
+        if (!hs[t]) { set_error("sx_comm_init_local: null handle"); return 1; }
+        comm_release(hs[t]);
+        CommState *c = new CommState();
+        hs[t]->comm_state = c;
+        if (configure(hs[t], c, n, t, cell0, ncells, mode)) return 1;
+    }
+    return 0;
+}
+
+int sx_exchange_local(sx_handle **hs, int32_t n) {
+    clear_error();
+    if (!hs || n < 1) { set_error("sx_exchange_local: invalid argument"); return 1; }
+    std::vector<CommState *> cs(n);
+    for (int t = 0; t < n; t++) {
+        if (!hs[t] || !hs[t]->comm_state) { set_error("sx_exchange_local: call sx_comm_init_local first"); return 1; }
+        cs[t] = (CommState *)hs[t]->comm_state;
+        if (cs[t]->n != n || cs[t]->me != t) { set_error("sx_exchange_local: handles are not tiles 0..n-1 of one patch"); return 1; }
+    }
+    auto copy = [&](double *dst, const double *src, int64_t cnt, hipStream_t s) {
+        return cnt == 0 || hipMemcpyAsync(dst, src, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    };
+    // all tiles share one device; run everything on tile 0's stream so that the copies are ordered with the kernels
+    hipStream_t s0 = hs[0]->stream;
+    std::vector<hipStream_t> keep(n);
+    for (int t = 0; t < n; t++) { keep[t] = hs[t]->stream; hs[t]->stream = s0; }
+    int rc = 0;
+    if (cs[0]->mode == 0) {
+        for (int t = 0; t < n && !rc; t++) rc = sx_a2a_pack_b(hs[t], cs[t]->tile_buf);
+        for (int sdr = 0; sdr < n && !rc; sdr++)          // sender sdr -> receiver d: what ncclSend(sdr, d) / ncclRecv(d, sdr) move
+            for (int d = 0; d < n; d++) {
+                if (cs[sdr]->tile_cnt[d] != cs[d]->own_cnt[sdr]) { set_error("exchange geometry mismatch"); rc = 1; break; }
+                if (!copy(cs[d]->own_in + cs[d]->own_off[sdr], cs[sdr]->tile_buf + cs[sdr]->tile_off[d], cs[sdr]->tile_cnt[d], s0)) { set_error("hipMemcpyAsync failed"); rc = 1; break; }
+            }
+        for (int t = 0; t < n && !rc; t++) rc = sx_a2a_solve(hs[t], cs[t]->own_in, cs[t]->own_out);
+        for (int o = 0; o < n && !rc; o++)                // owner o -> tile t
+            for (int t = 0; t < n; t++)
+                if (!copy(cs[t]->tile_buf2 + cs[t]->tile_off[o], cs[o]->own_out + cs[o]->own_off[t], cs[o]->own_cnt[t], s0)) { set_error("hipMemcpyAsync failed"); rc = 1; break; }
+        for (int t = 0; t < n && !rc; t++) rc = sx_a2a_unpack_a(hs[t], cs[t]->tile_buf2);
+    } else {
+        const int64_t C = hs[0]->C;
+        for (int t = 1; t < n && !rc; t++) {              // halo rows t-1 -> t, then the halo add on t
+            const double *src = cs[t - 1]->gbuf + ((int64_t)(t - 1) * cs[t - 1]->max_rows + cs[t - 1]->ncells[t - 1]) * C;
+            if (!copy(cs[t]->halo, src, 3 * C, s0)) { set_error("hipMemcpyAsync failed"); rc = 1; break; }
+            rc = sx_halo_add(hs[t], cs[t]->halo);
+        }
+        for (int t = 0; t < n && !rc; t++)                // all-gather: every tile's block into every other tile's buffer
+            for (int o = 0; o < n; o++) {
+                if (o == t) continue;
+                const int64_t off = (int64_t)o * cs[o]->max_rows * C;
+                if (!copy(cs[t]->gbuf + off, cs[o]->gbuf + off, cs[o]->max_rows * C, s0)) { set_error("hipMemcpyAsync failed"); rc = 1; break; }
+            }
+        for (int t = 0; t < n && !rc; t++) rc = sx_spline_transform(hs[t]);
+    }
+    for (int t = 0; t < n; t++) hs[t]->stream = keep[t];
+    return rc;
+}
+
 int sx_exchange(sx_handle *h) {
     clear_error();
     if (!h || !h->comm_state) { set_error("sx_exchange: call sx_comm_init / sx_comm_attach first"); return 1; }

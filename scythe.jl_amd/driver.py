@@ -263,6 +263,23 @@ class LibExchange:
         self.tile.exchange()
 
 
+class LocalLibExchange:
+    """All tiles in this process on one GPU, exchange done inside libscythe_hip.so with the loopback transport
+    (sx_comm_init_local / sx_exchange_local): the RCCL path's buffer geometry and offsets with copies instead of sends."""
+
+    def __init__(self, layout: PatchLayout, tiles, mode):
+        import ctypes as C
+        from . import _lib as L
+        self._L, self.n = L, len(tiles)
+        self.hs = (C.c_void_p * self.n)(*[g._h for g in tiles])
+        c0 = (C.c_int32 * self.n)(*layout.cell0)
+        nc = (C.c_int32 * self.n)(*layout.ncells)
+        L.check(L.load().sx_comm_init_local(self.hs, self.n, c0, nc, {"a2a": 0, "gather": 1}[mode]))
+
+    def exchange_and_solve(self):
+        self._L.check(self._L.load().sx_exchange_local(self.hs, self.n))
+
+
 class ModelRun:
     """initialize_model + run_model state for one process (src/semiimplicit.jl:126-256)."""
 
@@ -294,6 +311,9 @@ class ModelRun:
         if use_dist and impl == "lib":
             self.exchange_kind = exchange
             self.exchange = LibExchange(self.layout, self.tiles[0], exchange, unique_id=unique_id)
+        elif not use_dist and impl == "lib" and num_tiles > 1:
+            self.impl = "lib"
+            self.exchange = LocalLibExchange(self.layout, self.tiles, exchange)
         elif num_tiles > 1:
             if exchange == "a2a":
                 self.exchange = (DistA2AExchange(self.layout, self.tiles[0], device) if use_dist

@@ -184,10 +184,12 @@ def hip_params(case, storage="f64"):
 class HipModel:
     """The product path: tiles are libscythe_hip handles, exchange on device buffers."""
 
-    def __init__(self, case, num_tiles=1, device="cuda", exchange="a2a", storage="f64"):
+    def __init__(self, case, num_tiles=1, device="cuda", exchange="a2a", storage="f64", impl="torch"):
+        """impl="lib" (num_tiles > 1): the exchange runs inside libscythe_hip.so through its loopback transport (the RCCL
+        path's buffers and offset tables, copies instead of sends); "torch": the Python-side stand-in (driver.Local*Exchange)."""
         import scythe_jl_amd as S
         self.gp, self.mp = hip_params(case, storage)
-        self.run = S.ModelRun(self.mp, num_tiles=num_tiles, device=device, exchange=exchange)
+        self.run = S.ModelRun(self.mp, num_tiles=num_tiles, device=device, exchange=exchange, impl=impl)
         vals = []
         for g in self.run.tiles:
             pts = S.getGridpoints(g)

@@ -8,8 +8,8 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-10     # north_star: fields within 1e-10 relative of the CPU reference
 
 
-def _run(case, nsteps, num_tiles=1, oracle_tiles=None, exchange="a2a"):
-    hip = cases.HipModel(case, num_tiles=num_tiles, exchange=exchange)
+def _run(case, nsteps, num_tiles=1, oracle_tiles=None, exchange="a2a", impl="torch"):
+    hip = cases.HipModel(case, num_tiles=num_tiles, exchange=exchange, impl=impl)
     orc = cases.OracleModel(case, tiles=oracle_tiles)
     if hip.A is not None:
         e0 = cases.rel_err(hip.A, orc.A)
@@ -133,11 +133,14 @@ def test_rlz_advection():
                                              (cases.rl_slab, {"num_cells": 10}, 3), (cases.rlz_hrbl, {"num_cells": 7}, 2),
                                              (cases.rz_semiimplicit, {"num_cells": 9}, 3)])
 @pytest.mark.parametrize("exchange", ["gather", "a2a"])
-def test_tiles_on_one_gpu_match_single_patch_oracle(maker, kw, ntiles, exchange):
+@pytest.mark.parametrize("impl", ["torch", "lib"])
+def test_tiles_on_one_gpu_match_single_patch_oracle(maker, kw, ntiles, exchange, impl):
     """Several tile handles on one GPU against the one-patch oracle: "gather" = halo + gather of owned rows + redundant
-    solve (the reference's protocol), "a2a" = transposed solve (pack / all-to-all / solve / all-to-all / unpack)."""
+    solve (the reference's protocol), "a2a" = transposed solve (pack / all-to-all / solve / all-to-all / unpack).
+    impl "lib": sx_exchange's own buffers and offset tables, driven through the library's loopback transport
+    (sx_exchange_local) - what ncclSend / ncclRecv move between ranks is copied between the handles instead."""
     case = maker(**kw)
-    assert _run(case, 4, num_tiles=ntiles, exchange=exchange) < TOL
+    assert _run(case, 4, num_tiles=ntiles, exchange=exchange, impl=impl) < TOL
 
 
 def test_check_nan_sees_a_nan_on_the_node_space_path():
