@@ -278,3 +278,39 @@ def test_euler_test_with_reference_state_built_from_a_sounding_file(tmp_path):
     assert not run.tiles[0].check_nan()
     assert cases.rel_err_per_var(run.physical(), ref.physical()) < TOL
     run.close()
+
+
+@pytest.mark.parametrize("maker,kw,ntiles", [(cases.rl_slab, {"num_cells": 10}, 3), (cases.rlz_hrbl, {"num_cells": 7}, 2), (cases.kat_r, {}, 2)])
+def test_index_maps_reproduce_the_shared_sum(maker, kw, ntiles):
+    """sx_index_maps (calcPatchMap / calcHaloMap, src/semiimplicit.jl:79-86) used exactly as the Julia glue of INTEGRATION.md
+    uses them - sharedSpectral[patchOwned] .= tileSpectral[tileOwned]; the next tile adds tileSpectral[tileHalo] at the
+    previous tile's patchHalo (:320-329) - must give the patch's B coefficients: the spline solve of that host-assembled
+    array equals the oracle's A."""
+    import scythe_jl_amd as S
+    case = maker(**kw)
+    orc = cases.OracleModel(case)
+    gp, mp = cases.hip_params(case)
+    run = S.ModelRun(mp, num_tiles=ntiles, device="cuda", exchange="gather")
+    shared = None
+    halo_prev = None
+    for g in run.tiles:
+        pts = S.getGridpoints(g)
+        g.set_physical_values(case["ic"](pts.reshape(len(pts), -1)))
+        g.spectralTransform_()
+        tb = g.spectral                                    # [s_tile, V], reference tile layout
+        po, to, ph, th = g.index_maps()
+        if shared is None:
+            shared = np.zeros((int(g.dims.s_patch), g.V), order="F")
+        shared[po - 1, :] = tb[to - 1, :]                  # :323
+        if halo_prev is not None:
+            idx, vals = halo_prev
+            shared[idx - 1, :] += vals                     # :329
+        halo_prev = (ph, tb[th - 1, :]) if len(ph) else None
+    assert halo_prev is None                               # the last tile owns all its rows
+    run.close()
+    one = S.ModelRun(mp, num_tiles=1, device="cuda")
+    g1 = one.tiles[0]
+    g1.set_patch_spectral_b(shared)
+    g1.splineTransform_()
+    assert cases.rel_err(g1.patchSpectral, orc.A) < TOL
+    one.close()
