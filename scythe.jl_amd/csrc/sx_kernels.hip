@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256)
 k_colmat_mfma(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ mats,
               const ColJob *__restrict__ jobs, int n_in, int K2, int64_t in_row, int64_t out_row, int row0) {
     constexpr int n_out = MT * 16;
+    constexpr int KSTEPS = MT * 4;          // K = n_in <= n_out in steps of 4, fully unrolled (rows beyond n_in contribute zeros)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = lane & 15, kk = lane >> 4;
     const int blk0 = (blockIdx.x * 4 + wave) * 16;
@@ -87,24 +88,32 @@ k_colmat_mfma(const double *__restrict__ in, double *__restrict__ out, const dou
     const double *src = in + (int64_t)(row0 + blockIdx.z) * in_row + job.in_off + blk;
     double *dst = out + (int64_t)blockIdx.z * out_row + job.out_off;
     const double *MTr = mats + job.mat_off;                // operator transposed: [n_in][n_out]
-    colmat_d4 acc[MT];
+    // Every B element (coefficient row k, block n) of this wave is requested before the first MFMA, and each tile's operator
+    // fragments (L2-resident) before that tile's chain: with the loads inside the K loop every step of 4 waited for its own
+    // round trip (11 in a row at b_zDim 43).
+    double b[KSTEPS];
 #pragma unroll
-    for (int t = 0; t < MT; t++) acc[t] = colmat_d4{0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < n_in; k0 += 4) {
-        const int k = k0 + kk;
-        const bool kin = k < n_in;
-        const double b = kin ? src[(int64_t)k * K2] : 0.0;                      // B[k][n]: coefficient row k, block n
-#pragma unroll
-        for (int t = 0; t < MT; t++) {
-            const double a = kin ? MTr[(int64_t)k * n_out + t * 16 + n] : 0.0;   // A[m = lane & 15][k], 128-byte rows
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-        }
+    for (int ks = 0; ks < KSTEPS; ks++) {
+        const int k = 4 * ks + kk;
+        b[ks] = (k < n_in) ? src[(int64_t)k * K2] : 0.0;
     }
-    if (blk0 + n < K2) {
+    const bool okc = blk0 + n < K2;
 #pragma unroll
-        for (int t = 0; t < MT; t++)
+    for (int t = 0; t < MT; t++) {
+        double a[KSTEPS];
 #pragma unroll
-            for (int r = 0; r < 4; r++) dst[(int64_t)(t * 16 + kk + 4 * r) * K2 + blk0 + n] = acc[t][r];
+        for (int ks = 0; ks < KSTEPS; ks++) {
+            const int k = 4 * ks + kk;
+            a[ks] = (k < n_in) ? MTr[(int64_t)k * n_out + t * 16 + n] : 0.0;      // A[m = lane & 15][k], 128-byte rows
+        }
+        colmat_d4 acc = colmat_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++)
+            if (4 * ks < n_in) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+        if (okc) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(int64_t)(t * 16 + kk + 4 * r) * K2 + blk0 + n] = acc[r];
+        }
     }
 }
 
