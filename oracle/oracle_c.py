@@ -1,9 +1,11 @@
 """
 TEST INFRASTRUCTURE — NOT PRODUCT CODE.
 
-ctypes driver for oracle/liboracle.so (scythe_oracle.c). The operators (basis tables, Cholesky factors,
-Chebyshev matrices) are taken from the dense definitions in oracle_np.py; the C side only applies them
-with loops, so moderate sizes finish in seconds and the same code is the "port" CPU baseline of bench.py.
+ctypes driver for oracle/liboracle.so (scythe_oracle.c + scythe_oracle_ops.c).  The C side builds its OWN operators
+(basis tables, boundary-condition projection + Cholesky factors, Chebyshev matrices, Helmholtz operator:
+scythe_oracle_ops.c, OPS = "c") and applies them with loops, so moderate sizes finish in seconds and the same code is the
+"port" CPU baseline of bench.py; with OPS = "numpy" the operators are taken from the dense definitions in oracle_np.py
+instead (the cross-check of the two constructions is tests/test_oracle_consistency.py).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
 import ctypes as C
@@ -14,6 +16,8 @@ from . import oracle_np as O
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+OPS = os.environ.get("ORACLE_OPS", "c")       # "c": scythe_oracle_ops.c builds the operators; "numpy": oracle_np.py's are handed in
+BC_CODE = {"R0": 0, "R1T0": 1, "R1T1": 2, "R1T2": 3, "R2T10": 4, "R2T20": 5, "R3": 6, "PERIODIC": 7}
 
 EQ_IDS = {"LinearAdvection1D": 0, "LinearAdvectionRZ": 1, "LinearAdvectionRL": 2, "LinearAdvectionRLZ": 3,
           "Oneway_ShallowWater_Slab": 4, "Twoway_ShallowWater_Slab": 5,
@@ -24,7 +28,8 @@ PAR_ORDER = ["g", "K", "Cd", "Hfree", "Hb", "f", "S1", "c_0", "Kh", "Um", "Vm", 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "scythe_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    src2 = os.path.join(_HERE, "scythe_oracle_ops.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(src2)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
 
@@ -37,6 +42,11 @@ def lib():
             build()
         _LIB = C.CDLL(so)
         _LIB.orc_num_threads.restype = C.c_int
+        _LIB.orc_ops_phi.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, P_D, P_D]
+        _LIB.orc_ops_wq.argtypes = [C.c_double, P_D]
+        _LIB.orc_ops_spline_class.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, P_I, P_I, P_I, P_I, P_D, P_D, P_D, P_D]
+        _LIB.orc_ops_cheb.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int] + [P_D] * 9
+        _LIB.orc_ops_helmholtz.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, P_D, P_D]
     return _LIB
 
 
@@ -69,6 +79,34 @@ def _pi(a):
     return a.ctypes.data_as(P_I)
 
 
+def c_cheb(grid, v):
+    """Chebyshev column operators of variable v built by scythe_oracle_ops.c: dict(z, M [3][N][Zb], CB [Zb][N], Vint, Vdz, Vrec)."""
+    g = grid
+    N, Zb = g.zDim, g.b_zDim
+    key = ("c_cheb", g.BCB[v], g.BCT[v])
+    if key not in g._cheb:
+        o = dict(z=np.zeros(N), M=np.zeros((3, N, Zb)), CB=np.zeros((Zb, N)), Vint=np.zeros((N, N)), Vdz=np.zeros((N, N)),
+                 Vrec=np.zeros((N, N)), T=np.zeros((N, N)), D1=np.zeros((N, N)), D2=np.zeros((N, N)))
+        rc = lib().orc_ops_cheb(g.zmin, g.zmax, N, Zb, BC_CODE[g.BCB[v]], BC_CODE[g.BCT[v]],
+                                *[_pd(o[k]) for k in ("z", "M", "CB", "Vint", "Vdz", "Vrec", "T", "D1", "D2")])
+        if rc:
+            raise ValueError("orc_ops_cheb failed (unsupported vertical BC?)")
+        g._cheb[key] = o
+    return g._cheb[key]
+
+
+def c_spline_class(grid, bcl, bcr):
+    g = grid
+    nb = g.b_rDim
+    nfree, per, rl, rr = (C.c_int() for _ in range(4))
+    gl, gr, Lband, Larrow = np.zeros((3, 2)), np.zeros((3, 2)), np.zeros((nb, 4)), np.zeros((3, nb))
+    rc = lib().orc_ops_spline_class(g.xmin, g.xmax, g.nc, g.l_q, BC_CODE[bcl], BC_CODE[bcr], C.byref(nfree), C.byref(per),
+                                    C.byref(rl), C.byref(rr), _pd(gl), _pd(gr), _pd(Lband), _pd(Larrow))
+    if rc:
+        raise ValueError("orc_ops_spline_class failed: %d" % rc)
+    return nfree.value, per.value, rl.value, rr.value, gl, gr, Lband, Larrow
+
+
 class TileOracle:
     """C-oracle view of one radial tile (cell0, ncells) of a numpy-oracle Grid."""
 
@@ -84,25 +122,36 @@ class TileOracle:
         k["kmax"] = np.ascontiguousarray(g.kmax[rr], dtype=np.int32)
         k["off"] = np.ascontiguousarray(g.off[rr], dtype=np.float64)
         k["pstart"] = np.ascontiguousarray(g.ringstart[rr] - g.ringstart[rr[0]], dtype=np.int64)
-        r = O.mish_points(g.xmin, g.DX, cell0, ncells)
-        spl = g.spline("R0", "R0")
         phi = np.zeros((3, len(rr), 4))
         m0 = np.zeros(len(rr), dtype=np.int32)
-        for i in range(len(rr)):
-            c = cell0 + i // 3
-            m0[i] = c
-            for d in range(3):
-                phi[d, i, :] = spl.basis(r[i:i + 1], d)[0, c:c + 4]
+        if OPS == "c":
+            buf = np.zeros(4)
+            for i in range(len(rr)):
+                c = cell0 + i // 3
+                m0[i] = c
+                for d in range(3):
+                    lib().orc_ops_phi(g.xmin, g.DX, c, i % 3, d, _pd(buf), None)
+                    phi[d, i, :] = buf
+            wq3 = np.zeros(3)
+            lib().orc_ops_wq(g.DX, _pd(wq3))
+            k["wq"] = np.tile(wq3, ncells)
+        else:
+            r = O.mish_points(g.xmin, g.DX, cell0, ncells)
+            spl = g.spline("R0", "R0")
+            for i in range(len(rr)):
+                c = cell0 + i // 3
+                m0[i] = c
+                for d in range(3):
+                    phi[d, i, :] = spl.basis(r[i:i + 1], d)[0, c:c + 4]
+            k["wq"] = np.tile(g.DX * O.QUAD_W, ncells)
         k["phi"], k["m0"] = phi, m0
-        k["wq"] = np.tile(g.DX * O.QUAD_W, ncells)
         if g.has_z:
             Mz = np.zeros((g.V, 3, g.zDim, g.b_zDim))
             for vi, v in enumerate(g.names):
-                ch = g.cheb(v)
                 for d in range(3):
-                    Mz[vi, d] = ch.M[d]
+                    Mz[vi, d] = c_cheb(g, v)["M"][d] if OPS == "c" else g.cheb(v).M[d]
             k["Mz"] = Mz
-            k["CBz"] = np.ascontiguousarray(g.cheb(g.names[0]).CBm)
+            k["CBz"] = np.ascontiguousarray(c_cheb(g, g.names[0])["CB"] if OPS == "c" else g.cheb(g.names[0]).CBm)
         else:
             k["Mz"] = np.ones((g.V, 3, 1, 1))
             k["CBz"] = np.ones((1, 1))
@@ -125,6 +174,9 @@ class TileOracle:
         Lband = np.zeros((nc_, nb, 4))
         Larrow = np.zeros((nc_, 3, nb))
         for ci, (bcl, bcr) in enumerate(keys):
+            if OPS == "c":
+                nfree[ci], per[ci], rl[ci], rr_[ci], gl[ci], gr[ci], Lband[ci], Larrow[ci] = c_spline_class(g, bcl, bcr)
+                continue
             s = g.spline(bcl, bcr)
             n = s.G.shape[0]
             nfree[ci] = n
@@ -205,19 +257,30 @@ class ModelOracle:
         self.Mint = self.Mdz = self.Mrec = np.zeros((1, 1))
         if g.has_z:
             hv = "h" if "h" in g.vars else g.names[0]
-            ch = g.cheb(hv)
-            self.Mint = np.ascontiguousarray(ch.Vint)
-            self.Mdz = np.ascontiguousarray(ch.Vdz)
+            if OPS == "c":
+                ch = c_cheb(g, hv)
+                self.Mint, self.Mdz = np.ascontiguousarray(ch["Vint"]), np.ascontiguousarray(ch["Vdz"])
+            else:
+                ch = g.cheb(hv)
+                self.Mint, self.Mdz = np.ascontiguousarray(ch.Vint), np.ascontiguousarray(ch.Vdz)
         if self.semi:
-            chx = g.cheb("xi")
-            self.Mdz = np.ascontiguousarray(chx.Vdz)
-            self.Mrec = np.ascontiguousarray(chx.Vrec)
+            if OPS == "c":
+                chx = c_cheb(g, "xi")
+                self.Mdz, self.Mrec = np.ascontiguousarray(chx["Vdz"]), np.ascontiguousarray(chx["Vrec"])
+            else:
+                chx = g.cheb("xi")
+                self.Mdz, self.Mrec = np.ascontiguousarray(chx.Vdz), np.ascontiguousarray(chx.Vrec)
 
     def _semi_mats(self, tau):
         if tau not in self._mats:
             g = self.g
-            chw = g.cheb("w")
-            W, X = O.semi_matrices(chw, self.par[PAR_ORDER.index("Pxi_bar")], tau)
+            pxi = self.par[PAR_ORDER.index("Pxi_bar")]
+            if OPS == "c":
+                W, X = np.zeros((g.zDim, g.zDim)), np.zeros((g.zDim, g.zDim))
+                if lib().orc_ops_helmholtz(g.zmin, g.zmax, g.zDim, pxi, tau, _pd(W), _pd(X)):
+                    raise ValueError("orc_ops_helmholtz: singular matrix")
+            else:
+                W, X = O.semi_matrices(g.cheb("w"), pxi, tau)
             self._mats[tau] = (np.ascontiguousarray(W), np.ascontiguousarray(X))
         return self._mats[tau]
 

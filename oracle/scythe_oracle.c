@@ -5,9 +5,10 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  *
  * It applies, with ordinary loops (OpenMP over rings / spectral blocks / columns - the axes the reference
- * threads over, src/semiimplicit.jl:309), the operators whose dense definitions live in oracle/oracle_np.py
- * (basis tables, Cholesky factors, Chebyshev matrices are handed in by the Python side), in the reference's
- * own array layouts: physical[point, var, deriv] and spectral[index, var], column-major as in Julia.
+ * threads over, src/semiimplicit.jl:309), operators given as plain arrays (basis tables, Cholesky factors, Chebyshev
+ * matrices: built by scythe_oracle_ops.c, or - for the cross-check - taken from the dense definitions of
+ * oracle/oracle_np.py), in the reference's own array layouts: physical[point, var, deriv] and spectral[index, var],
+ * column-major as in Julia.
  *
  *   orc_forward        spectralTransform!(tile)   src/semiimplicit.jl:734   (Springsteel, external)
  *   orc_spline_solve   splineTransform!           src/semiimplicit.jl:285   (Springsteel, external)

@@ -211,3 +211,59 @@ def test_helmholtz_lu_path_is_the_reference_arithmetic_and_agrees_with_the_exten
     pe, pl = m_ext.physical(), m_lu.physical()
     for v in range(pe.shape[1]):
         assert np.abs(pe[:, v, 0] - pl[:, v, 0]).max() < 1e-12 * np.abs(pe[:, v, 0]).max()
+
+
+# ----------------------------------------------------------------------------- two operator constructions
+def test_c_oracle_builds_its_own_operators_and_they_match_the_numpy_definition():
+    """scythe_oracle_ops.c constructs basis tables, quadrature weights, the boundary-condition projection + Cholesky factor,
+    the Chebyshev column operators and the Helmholtz operator from the definitions, independently of oracle_np.py.  Operator
+    by operator the two constructions agree to rounding - so test_c_port_equals_numpy_definition (above; OPS = "c" is the
+    default) compares two constructions as well as two ways of applying them."""
+    from oracle import oracle_c as OC
+    assert OC.OPS == "c"
+    g = cases.oracle_grid(cases.rlz_hrbl(num_cells=9, zDim=20))
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    for v in ("h", "ub"):
+        c, n = OC.c_cheb(g, v), g.cheb(v)
+        assert np.array_equal(c["z"], n.z)
+        for a, b in ((c["M"][0], n.M[0]), (c["M"][1], n.M[1]), (c["M"][2], n.M[2]), (c["CB"], n.CBm), (c["Vint"], n.Vint),
+                     (c["Vdz"], n.Vdz), (c["Vrec"], n.Vrec), (c["T"], n.dct_matrix()), (c["D1"], n.dct_1st_derivative()),
+                     (c["D2"], n.dct_2nd_derivative())):
+            assert rel(a, b) < 1e-14
+    for bcl, bcr in (("R0", "R0"), ("R1T0", "R1T1"), ("R1T1", "R0"), ("R2T10", "R3"), ("R1T2", "R2T20"), ("PERIODIC", "PERIODIC")):
+        nfree, per, rl, rr, gl, gr, Lb, La = OC.c_spline_class(g, bcl, bcr)
+        s = g.spline(bcl, bcr)
+        Lc, n, nb = s.cho, s.G.shape[0], g.b_rDim
+        assert nfree == n and per == (bcl == "PERIODIC")
+        band = np.zeros((nb, 4))
+        for i in range(n):
+            for q in range(4):
+                if i - q >= 0:
+                    band[i, 3 - q] = Lc[i, i - q]
+        assert rel(Lb, band) < 1e-13
+        if per:
+            assert rel(La[:, :n], Lc[n - 3:, :]) < 1e-13
+        else:
+            assert (rl, rr) == (O.BC_RANK[bcl], O.BC_RANK[bcr])
+            for i in range(rl):
+                assert (gl[i, 0], gl[i, 1]) == (s.G[0, i], s.G[1, i])
+            for i in range(rr):
+                assert (gr[i, 0], gr[i, 1]) == (s.G[n - 1, nb - 1 - i], s.G[n - 2, nb - 1 - i])
+    # basis values and weights
+    buf, w3 = np.zeros(4), np.zeros(3)
+    spl = g.spline("R0", "R0")
+    for c in (0, 4, 8):
+        for mu in range(3):
+            x = O.mish_points(g.xmin, g.DX, c, 1)[mu:mu + 1]
+            for d in range(3):
+                OC.lib().orc_ops_phi(g.xmin, g.DX, c, mu, d, OC._pd(buf), None)
+                ref = spl.basis(x, d)[0, c:c + 4]
+                assert np.abs(buf - ref).max() <= 1e-15 * max(np.abs(ref).max(), 1e-300)
+    OC.lib().orc_ops_wq(g.DX, OC._pd(w3))
+    assert np.abs(w3 - g.DX * O.QUAD_W).max() < 1e-15 * g.DX
+    # Helmholtz operator (semi-implicit solve)
+    gz = cases.oracle_grid(cases.rz_semiimplicit(zDim=24))
+    W, X = np.zeros((24, 24)), np.zeros((24, 24))
+    assert OC.lib().orc_ops_helmholtz(gz.zmin, gz.zmax, 24, 1.2e5, 2.5, OC._pd(W), OC._pd(X)) == 0
+    Wn, Xn = O.semi_matrices(gz.cheb("w"), 1.2e5, 2.5)
+    assert rel(W, Wn) < 1e-13 and rel(X, Xn) < 1e-13
