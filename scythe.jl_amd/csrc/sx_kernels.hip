@@ -1451,8 +1451,9 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     // ... then everything else, needed only after the column operators
     NODE_V(qh, rv[2], 0) NODE_D(qhl, rd[3], 0, a.s_l) NODE_V(qug, rv[3], 1) NODE_D(qugl, rd[4], 1, a.s_l) NODE_V(qvg, rv[4], 2) NODE_D(qvgl, rd[5], 2, a.s_l)
     NODE_D(qubl, rd[6], 3, a.s_l) NODE_D(qubll, rd[7], 3, a.s_ll) NODE_D(qvbll, rd[8], 4, a.s_ll)
-    // tendency history: ring 0 behind the operator fragments (in flight during the MFMA phase), rings 1 and 2 at the start
-    // of the final phase (in flight while ring 0 is finished) - fetched earlier it would only occupy registers.  WIDE:
+    // tendency history: ring 0 with the entry burst, ring 1 behind the first operator fragments (in flight during the MFMA
+    // phase and ring 0), ring 2 at the start of the final phase; the fragments come in two chunks of 8 so that all of
+    // this fits the 256 registers of a two-waves-per-SIMD kernel.  WIDE:
     // expdot_nm1 / nm2 of a variable travel as one pair; before step 3 the buffers exist but hold no history yet.
     double e1h[MUBAR][5], e2h[MUBAR][5];
     dbl2v rh[MUBAR][5];
@@ -1472,6 +1473,7 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
             else { e1h[mu][v] = 0.0; e2h[mu][v] = 0.0; }                                           \
         }                                                                                          \
     }
+    HIST(0)
     SX_LOAD_FENCE();
 
     // ---- inputs of the column operators
@@ -1514,7 +1516,7 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
         const int wave = threadIdx.x >> 6;
         constexpr int RT = NZ / 16, NW = LAM * NZ / 64;
         constexpr int UPW = (RT * NT + NW - 1) / NW;         // (row tile, column tile) units per wave
-        constexpr int KC = (NZ / 4 > 16) ? 8 : NZ / 4;       // operator fragments fetched per chunk (register budget)
+        constexpr int KC = 8;                                // operator fragments fetched per chunk (register budget)
         mfma_d4 c0[UPW], c1[UPW], c2[UPW];
 #pragma unroll
         for (int uu = 0; uu < UPW; uu++) {
@@ -1532,10 +1534,10 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
                         ad[ks] = a.MdzT[ao + (int64_t)(kc + ks) * 4 * NZ];
                     }
                     if (uu == 0 && kc == 0) {
-                        // ring 0's history goes out BEHIND the first operator fragments: the memory counter retires in issue
+                        // ring 1's history goes out BEHIND the first operator fragments: the memory counter retires in issue
                         // order, so fragments issued after it would wait for its HBM latency before the first MFMA
                         SX_LOAD_FENCE();
-                        HIST(0)
+                        HIST(1)
                         SX_LOAD_FENCE();
                     }
 #pragma unroll
@@ -1547,7 +1549,7 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
                 }
             }
         }
-        if (RT * NT < NW && wave >= RT * NT) { HIST(0) }      // waves without a unit (never at the shipped shapes)
+        if (RT * NT < NW && wave >= RT * NT) { HIST(1) }      // waves without a unit (never at the shipped shapes)
         SX_STAMP(3);
         if (ALIAS) __syncthreads();
 #pragma unroll
@@ -1564,7 +1566,6 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
     }
     __syncthreads();
     SX_STAMP(4);
-    HIST(1)
     HIST(2)
     SX_LOAD_FENCE();
     NODE_TAKE(qh, rv[2]) NODE_TAKE(qhl, rd[3]) NODE_TAKE(qug, rv[3]) NODE_TAKE(qugl, rd[4]) NODE_TAKE(qvg, rv[4]) NODE_TAKE(qvgl, rd[5])
