@@ -1842,7 +1842,7 @@ static void launch_physics_t(sx_handle *h, int t, int part) {
             a.col0 = split; a.col1 = h->Nh;
             const int ncell = (h->nrings - h->R_in) / MUBAR;         // R_in is a multiple of 3 (sx_create)
 #ifdef SX_PHASES
-            a.dbg = phases_buffer((int64_t)ncell * (h->uniform_L / (h->nz == 64 ? 4 : h->nz == 32 ? 8 : 2)));
+            a.dbg = phases_buffer((int64_t)ncell * (h->uniform_L / (h->nz == 32 ? 8 : 4)));
 #endif
 #define CELL_LAUNCH(NZ_, LAM_)                                                                                                     \
             do {                                                                                                                      \
@@ -1851,7 +1851,7 @@ static void launch_physics_t(sx_handle *h, int t, int part) {
             } while (0)
             if (h->nz == 64) CELL_LAUNCH(64, 4);      // LAM 2: 0.55 ms (6 of 16 MFMA columns, 1 KB chunks); 4: 0.41 ms
             else if (h->nz == 32) CELL_LAUNCH(32, 8);
-            else CELL_LAUNCH(128, 2);
+            else CELL_LAUNCH(128, 4);   // 512 threads, one workgroup per CU: 12 of 16 MFMA columns (LAM 2: 6 of 16, 3.23 vs 2.58 ms at config 5)
 #undef CELL_LAUNCH
             HIPCHK(hipGetLastError());
             timer_end(h);
