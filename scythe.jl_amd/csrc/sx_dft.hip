@@ -81,103 +81,110 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
         const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
         const double f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
         __syncthreads();                                        // the previous set has been consumed (and twl is complete)
-        for (int e = tid; e < DZC * K4; e += blockDim.x) {
-            const int k = e % K4, zz = e / K4;
-            double cr = 0.0, ci = 0.0;
-            if (zz < zc && k <= km) {
-                const double *a = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + zz)) * K2;
-                if (k == 0) {
-                    cr = f0 * a[0] + f1 * a[azrow] + f2 * a[2 * azrow] + f3 * a[3 * azrow];
-                } else {
-                    const int b = 2 * k;
-                    cr = f0 * a[b] + f1 * a[azrow + b] + f2 * a[2 * azrow + b] + f3 * a[3 * azrow + b];
-                    ci = f0 * a[b + 1] + f1 * a[azrow + b + 1] + f2 * a[2 * azrow + b + 1] + f3 * a[3 * azrow + b + 1];
-                    const double2 w = phr[k];                   // e^{+i k off}
-                    const double tr = cr * w.x - ci * w.y;
-                    ci = 2.0 * (cr * w.y + ci * w.x);
-                    cr = 2.0 * tr;
+        {
+            // thread -> (level zz, wavenumber kq + 32 b): the 4 radial rows of a wavenumber come as 16-byte (Re, Im) pairs, and
+            // the loads of KB wavenumbers are issued together (the rolled form waited for each wavenumber's 8 scalar loads
+            // on its own - 8 round trips per coefficient set, as long as the matrix-core phase itself)
+            constexpr int KB = 4;
+            const int zz = tid >> 5, kq = tid & 31;              // 512 threads = 16 levels x 32 wavenumbers
+            const bool zin = zz < zc;
+            const double *a = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + (zin ? zz : 0))) * K2;
+            for (int k0 = 0; k0 < K4; k0 += 32 * KB) {
+                double2 raw[KB][4];
+#pragma unroll
+                for (int b = 0; b < KB; b++) {
+                    const int k = k0 + kq + 32 * b;
+                    const int kc = min(k, km);                    // valid address for the padding rows (value dropped)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) raw[b][r] = *reinterpret_cast<const double2 *>(a + r * azrow + 2 * kc);
+                }
+#pragma unroll
+                for (int b = 0; b < KB; b++) {
+                    const int k = k0 + kq + 32 * b;
+                    if (k >= K4 || zz >= DZC) continue;
+                    double cr = 0.0, ci = 0.0;
+                    if (zin && k <= km) {
+                        cr = f0 * raw[b][0].x + f1 * raw[b][1].x + f2 * raw[b][2].x + f3 * raw[b][3].x;
+                        if (k > 0) {
+                            ci = f0 * raw[b][0].y + f1 * raw[b][1].y + f2 * raw[b][2].y + f3 * raw[b][3].y;
+                            const double2 w = phr[k];               // e^{+i k off}
+                            const double tr = cr * w.x - ci * w.y;
+                            ci = 2.0 * (cr * w.y + ci * w.x);
+                            cr = 2.0 * tr;
+                        }
+                    }
+                    Cc[k * CST + zz] = cr;
+                    Cs[k * CST + zz] = ci;
                 }
             }
-            Cc[k * CST + zz] = cr;
-            Cs[k * CST + zz] = ci;
         }
         __syncthreads();
 
         const int i = lane & 15, kk = lane >> 4;
-        // two row tiles of the half ring per pass: B operands (and their derivative factors) are read once for both
-        for (int mt = wave; mt * 16 <= Lh; mt += 2 * nw) {
-            const int mtb = mt + nw;
-            const bool two = mtb * 16 <= Lh;
-            RowPair rp;
-            rp.init(min(mt * 16 + i, Lh), min(mtb * 16 + i, Lh), kk, L);
+        // Quarter-wave form: with L a multiple of 4, cos(k theta (L/2 - l)) = (-1)^k cos(k theta l) and
+        // sin(k theta (L/2 - l)) = -(-1)^k sin(k theta l), so only the points l = 0 .. L/4 are transformed, the even and the
+        // odd wavenumbers in separate accumulators (Pe, Po, Qe, Qo), and each row gives FOUR ring points:
+        //   x[l]       = (Pe + Po) - (Qe + Qo)        x[L - l]   = (Pe + Po) + (Qe + Qo)
+        //   x[L/2 - l] = (Pe - Po) + (Qe - Qo)        x[L/2 + l] = (Pe - Po) - (Qe - Qo)
+        // - half the matrix-core work of the half-ring form (this transform is compute-bound: DESIGN.md 7).
+        const int Lq = L / 4;
+        for (int mt = wave; mt * 16 <= Lq; mt += nw) {
+            const int lrow = min(mt * 16 + i, Lq);                 // A operand: this lane's ring point
             dft_d4 z4 = {0.0, 0.0, 0.0, 0.0};
-            dft_d4 pu0 = z4, qu0 = z4, pl0 = z4, ql0 = z4, pll0 = z4, qll0 = z4;
-            dft_d4 pu1 = z4, qu1 = z4, pl1 = z4, ql1 = z4, pll1 = z4, qll1 = z4;
-            double kd = (double)kk;                             // this lane's wavenumber k = 4 js + kk
-            for (int js = 0; js < K4 / 4; js++) {
-                const double2 t0 = twl[rp.m0], t1 = twl[rp.m1];
-                const double bc = Cc[(4 * js + kk) * CST + i], bs = Cs[(4 * js + kk) * CST + i];
-                if (need0) {
-                    pu0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, pu0, 0, 0, 0);
-                    qu0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, qu0, 0, 0, 0);
-                    if (two) {
-                        pu1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.x, bc, pu1, 0, 0, 0);
-                        qu1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.y, bs, qu1, 0, 0, 0);
+            dft_d4 pu[2] = {z4, z4}, qu[2] = {z4, z4}, pl[2] = {z4, z4}, ql[2] = {z4, z4}, pll[2] = {z4, z4}, qll[2] = {z4, z4};
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                if (km < par) continue;
+                const int nk = (km - par) / 2 + 1;                  // wavenumbers of this parity
+                // this lane's wavenumber k = 8 js + 2 kk + par; angle index (k l) mod L advances by 8 l per step
+                int m = (int)(((int64_t)(2 * kk + par) * lrow) % L);
+                const int sm8 = (int)(((int64_t)8 * lrow) % L);
+                double kd = (double)(2 * kk + par);
+                for (int js = 0; js * 4 < nk; js++) {
+                    const int k = 8 * js + 2 * kk + par;
+                    const bool kin = k < K4;
+                    const double2 t0 = twl[m];
+                    const double bc = kin ? Cc[k * CST + i] : 0.0, bs = kin ? Cs[k * CST + i] : 0.0;
+                    if (need0) {
+                        pu[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, pu[par], 0, 0, 0);
+                        qu[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, qu[par], 0, 0, 0);
                     }
-                }
-                if (needl) {                                    // i k (cr + i ci): cosine part -k ci, sine part k cr
-                    const double blc = -kd * bs, bls = kd * bc;
-                    pl0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, blc, pl0, 0, 0, 0);
-                    ql0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bls, ql0, 0, 0, 0);
-                    if (two) {
-                        pl1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.x, blc, pl1, 0, 0, 0);
-                        ql1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.y, bls, ql1, 0, 0, 0);
+                    if (needl) {                                    // i k (cr + i ci): cosine part -k ci, sine part k cr
+                        pl[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, -kd * bs, pl[par], 0, 0, 0);
+                        ql[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, kd * bc, ql[par], 0, 0, 0);
                     }
-                }
-                if (needll) {
-                    const double k2 = -(kd * kd);
-                    pll0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, k2 * bc, pll0, 0, 0, 0);
-                    qll0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, k2 * bs, qll0, 0, 0, 0);
-                    if (two) {
-                        pll1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.x, k2 * bc, pll1, 0, 0, 0);
-                        qll1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.y, k2 * bs, qll1, 0, 0, 0);
+                    if (needll) {
+                        const double k2 = -(kd * kd);
+                        pll[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, k2 * bc, pll[par], 0, 0, 0);
+                        qll[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, k2 * bs, qll[par], 0, 0, 0);
                     }
+                    kd += 8.0;
+                    m += sm8;
+                    if (m >= L) m -= L;
                 }
-                kd += 4.0;
-                rp.step(L);
             }
-            // D tile: lane holds column n = lane & 15 (level), rows (lane >> 4) + 4 r (points l of the half ring);
-            // x[l] = P - Q and, for 0 < l < L/2, x[L - l] = P + Q
+            // D tile: lane holds column n = lane & 15 (level), rows (lane >> 4) + 4 r (points l of the quarter ring)
             if (i < zc) {
                 auto put = [&](int slot, int64_t pt, double val) {
                     if (slot == 0) phys.val[(int64_t)v * N + pt] = val;
                     else phys.der[((int64_t)(slot - 1) * V + v) * N + pt] = (ST)val;
                 };
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    if (half == 1 && !two) break;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int lo = (half ? mtb : mt) * 16 + kk + 4 * r;
-                        if (lo > Lh) continue;
-                        const bool mirror = lo > 0 && lo < Lh;
-                        const int64_t pa = (p0 + lo) * nz + z0 + i, pb = (p0 + (L - lo)) * nz + z0 + i;
-                        if (need0) {
-                            const double P = half ? pu1[r] : pu0[r], Q = half ? qu1[r] : qu0[r];
-                            put(slot0, pa, P - Q);
-                            if (mirror) put(slot0, pb, P + Q);
-                        }
-                        if (needl) {
-                            const double P = half ? pl1[r] : pl0[r], Q = half ? ql1[r] : ql0[r];
-                            put(s_l, pa, P - Q);
-                            if (mirror) put(s_l, pb, P + Q);
-                        }
-                        if (needll) {
-                            const double P = half ? pll1[r] : pll0[r], Q = half ? qll1[r] : qll0[r];
-                            put(s_ll, pa, P - Q);
-                            if (mirror) put(s_ll, pb, P + Q);
-                        }
+                auto put4 = [&](int slot, int lo, double Pe, double Po, double Qe, double Qo) {
+                    const double Ps = Pe + Po, Pd = Pe - Po, Qs = Qe + Qo, Qd = Qe - Qo;
+                    put(slot, (p0 + lo) * nz + z0 + i, Ps - Qs);
+                    if (lo > 0) put(slot, (p0 + (L - lo)) * nz + z0 + i, Ps + Qs);
+                    if (lo < Lq) {
+                        put(slot, (p0 + (Lh - lo)) * nz + z0 + i, Pd + Qd);
+                        if (lo > 0) put(slot, (p0 + (Lh + lo)) * nz + z0 + i, Pd - Qd);
                     }
+                };
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int lo = mt * 16 + kk + 4 * r;
+                    if (lo > Lq) continue;
+                    if (need0) put4(slot0, lo, pu[0][r], pu[1][r], qu[0][r], qu[1][r]);
+                    if (needl) put4(s_l, lo, pl[0][r], pl[1][r], ql[0][r], ql[1][r]);
+                    if (needll) put4(s_ll, lo, pll[0][r], pll[1][r], qll[0][r], qll[1][r]);
                 }
             }
         }
