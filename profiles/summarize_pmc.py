@@ -22,7 +22,7 @@ def timer_name(kernel):
         return "k_node_fft" if targs[2] in ("true", "1") else "k_rl_inverse"
     if base == "k_phys_hrbl_mfma":           # ring-wise HRBL kernel: the inner rings when the cell kernel takes the rest
         return "k_phys_hrbl_inner"
-    return {"k_fl_forward_fft": "k_fl_forward", "k_colmat": "k_zinv", "k_colmat_mfma": "k_zinv", "k_sbw": "k_sbz",
+    return {"k_fl_forward_fft": "k_fl_forward", "k_colmat": "k_zinv", "k_colmat_mfma": "k_zinv", "k_sbw": "k_sbz", "k_sbw_mfma": "k_sbz",
             "k_phys_hrbl_cell": "k_phys_hrbl"}.get(base, base)
 
 
