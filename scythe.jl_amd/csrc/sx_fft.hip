@@ -3,9 +3,9 @@
 //
 // One workgroup = (z-chunk of 16 levels, variable, ring).  Two vertical levels are packed into one complex
 // transform (level 2p -> real part, 2p+1 -> imaginary part): 8 complex transforms per derivative slot and chunk.
-// A transform of length L is owned by L/4 lanes of ONE wave (L <= 256), so every pass is wave-local: in-place radix-4
+// A transform of length L is owned by min(L/4, 64) lanes of ONE wave, so every pass is wave-local: in-place radix-4
 // autosort passes through a 16 B x L LDS region (+ one radix-2 pass when log2 L is odd), twiddles held in registers,
-// no workgroup barrier inside a transform.
+// no workgroup barrier inside a transform (at L = 512 a lane carries two butterflies per pass).
 //   inverse: the last pass stores straight to the reference physical layout (z innermost): each lane writes the
 //            16-byte (z, z+1) pair of its ring points; the 8 waves of the workgroup complete every 128-byte line.
 //   forward: the workgroup first stages the [ring point][16 levels] tile through LDS with full 128-byte loads.
@@ -22,13 +22,19 @@ namespace sx {
         if (e_ != hipSuccess) set_error(std::string(#x) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
-// z levels per workgroup (FZC) and complex transforms per slot and workgroup (FNP = FZC / 2).  A transform of length L
-// is owned by L/4 lanes: one wave up to L = 256 (16 levels per 512-thread workgroup, wave-local passes), two waves for
-// L = 512 (8 levels, the passes then synchronise through an LDS-only workgroup barrier).
+// z levels per workgroup (FZC) and complex transforms per slot and workgroup (FNP = FZC / 2).  A transform of length L is
+// owned by LPT = min(L / 4, 64) lanes of ONE wave, so every pass is wave-local; for L = 512 a lane carries NB = 2 radix-4
+// butterflies per pass (and NK = 4 wavenumbers while staging) instead of spreading the transform over two waves that had to
+// meet at a workgroup barrier after every pass.  16 levels per workgroup at every L, so that a ring point's levels leave and
+// arrive as whole 128-byte lines (8 levels per workgroup - 64-byte pieces - held the L = 512 kernels at 3.2 TB/s).
 // SKEW: complex elements between transform regions (bank spreading when L < 256; 0 at L = 512 so that the two LDS sets
 // of the inverse are exactly 64 KB).
 template <int LOGL> struct FftCfg {
-    static constexpr int FZC = (LOGL <= 8) ? 16 : 8, FNP = FZC / 2, LOGZ = (LOGL <= 8) ? 4 : 3, SKEW = (LOGL <= 8) ? 2 : 0;
+    static constexpr int FZC = 16, FNP = FZC / 2, LOGZ = 4, SKEW = (LOGL <= 8) ? 2 : 0;
+    static constexpr int L4 = (1 << LOGL) / 4;
+    static constexpr int LPT = L4 > 64 ? 64 : L4;      // lanes per transform
+    static constexpr int NB = L4 / LPT;                // radix-4 butterflies per lane and pass
+    static constexpr int NK = 2 * NB;                  // wavenumbers (k < L / 2) per lane
 };
 
 // phase stamps of the diagnostic build (-DSX_PHASES): [workgroup][8] cycle counts of the NODE inverse kernel, dumped by sx_destroy
@@ -60,19 +66,13 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// orders the LDS traffic of the lanes that share one transform
-template <int LOGL>
-__device__ __forceinline__ void pass_sync() {
-    if (LOGL <= 8) wave_sync();
-    else lds_barrier();
-}
-
 template <int LOGL>
 struct Twiddles {
-    static constexpr int L = 1 << LOGL, T = L / 4, NP4 = LOGL / 2;
+    static constexpr int L = 1 << LOGL, NP4 = LOGL / 2, LPT = FftCfg<LOGL>::LPT, NB = FftCfg<LOGL>::NB;
     double2 w1[NP4 > 1 ? NP4 - 1 : 1];     // w2 = w1^2, w3 = w1^3 are formed on the fly (registers are the scarce resource)
-    double2 r2a, r2b;
-    // SIGN = +1: e^{+i...} (inverse), -1: forward
+    double2 r2[2 * NB];                    // final radix-2 pass (odd log2 L): butterflies j = t + c LPT
+    // SIGN = +1: e^{+i...} (inverse), -1: forward.  t = lane within the transform.  The radix-4 twiddle of butterfly
+    // j = t + b LPT depends on j mod Ns only, and Ns <= LPT in every radix-4 pass, so all NB butterflies of a lane share it.
     template <int SIGN>
     __device__ void init(const double2 *__restrict__ twg, int t) {
         int Ns = 4;
@@ -84,15 +84,18 @@ struct Twiddles {
             Ns <<= 2;
         }
         if (LOGL & 1) {
-            r2a = twg[t]; r2b = twg[t + T];
-            if (SIGN < 0) { r2a.y = -r2a.y; r2b.y = -r2b.y; }
+#pragma unroll
+            for (int c = 0; c < 2 * NB; c++) {
+                r2[c] = twg[t + c * LPT];
+                if (SIGN < 0) r2[c].y = -r2[c].y;
+            }
         }
     }
 };
 
-// In-place radix-4 passes on X (L complex, owned by T = L/4 lanes of one wave, lane index t).
+// In-place radix-4 passes on X (L complex, owned by LPT lanes of one wave, lane index t, NB butterflies per lane).
 // All passes but the last are done here; `last` receives the outputs of the final pass:
-//   last(index, value) for the 4 (radix-4 ending) or 2 x 2 (radix-2 ending) outputs of this lane.
+//   last(index, value) for the 4 (radix-4 ending) or 2 (radix-2 ending) outputs of each butterfly of this lane.
 struct NoSink {
     __device__ void operator()(int, double2) const {}
 };
@@ -100,45 +103,62 @@ struct NoSink {
 // TO_LDS = true: the final pass is written back to X as well (natural order), `last` is not called.
 template <int LOGL, int SIGN, bool TO_LDS = false, class F = NoSink>
 __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw, int t, bool active, F last = F()) {
-    constexpr int L = 1 << LOGL, T = L / 4, NP4 = LOGL / 2;
+    constexpr int L = 1 << LOGL, NBF = L / 4, NP4 = LOGL / 2, LPT = FftCfg<LOGL>::LPT, NB = FftCfg<LOGL>::NB;
     int Ns = 1;
 #pragma unroll
     for (int p = 0; p < NP4; p++) {
-        double2 y0, y1, y2, y3;
-        int j0 = 0;
+        double2 y0[NB], y1[NB], y2[NB], y3[NB];
+        int j0[NB];
+        const int k = t & (Ns - 1);
         if (active) {
-            const int k = t & (Ns - 1);
-            double2 v0 = X[t], v1 = X[t + T], v2 = X[t + 2 * T], v3 = X[t + 3 * T];
-            if (p > 0) {
-                const double2 w1 = tw.w1[p - 1], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
-                v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const int j = t + b * LPT;
+                double2 v0 = X[j], v1 = X[j + NBF], v2 = X[j + 2 * NBF], v3 = X[j + 3 * NBF];
+                if (p > 0) {
+                    const double2 w1 = tw.w1[p - 1], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                    v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
+                }
+                const double2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), t3 = cmuli(csub(v1, v3), SIGN);
+                y0[b] = cadd(t0, t2); y1[b] = cadd(t1, t3); y2[b] = csub(t0, t2); y3[b] = csub(t1, t3);
+                j0[b] = ((j - k) << 2) + k;
             }
-            const double2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), t3 = cmuli(csub(v1, v3), SIGN);
-            y0 = cadd(t0, t2); y1 = cadd(t1, t3); y2 = csub(t0, t2); y3 = csub(t1, t3);
-            j0 = ((t - k) << 2) + k;
         }
         if (!TO_LDS && p == NP4 - 1 && !(LOGL & 1)) {
-            if (active) { last(j0, y0); last(j0 + Ns, y1); last(j0 + 2 * Ns, y2); last(j0 + 3 * Ns, y3); }
+            if (active) {
+#pragma unroll
+                for (int b = 0; b < NB; b++) { last(j0[b], y0[b]); last(j0[b] + Ns, y1[b]); last(j0[b] + 2 * Ns, y2[b]); last(j0[b] + 3 * Ns, y3[b]); }
+            }
             return;
         }
-        pass_sync<LOGL>();      // every lane has read its inputs before any lane overwrites them
-        if (active) { X[j0] = y0; X[j0 + Ns] = y1; X[j0 + 2 * Ns] = y2; X[j0 + 3 * Ns] = y3; }
-        pass_sync<LOGL>();
+        wave_sync();      // every lane has read its inputs before any lane overwrites them
+        if (active) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) { X[j0[b]] = y0[b]; X[j0[b] + Ns] = y1[b]; X[j0[b] + 2 * Ns] = y2[b]; X[j0[b] + 3 * Ns] = y3[b]; }
+        }
+        wave_sync();
         Ns <<= 2;
     }
-    if (LOGL & 1) {       // final radix-2 pass, Ns = L/2: butterflies j = t and t + T
-        double2 a0, a1, b0, b1;
+    if (LOGL & 1) {       // final radix-2 pass, Ns = L/2: butterfly j works on X[j], X[j + L/2] in place
+        double2 lo[2 * NB], hi[2 * NB];
         if (active) {
-            a0 = X[t]; a1 = cmul(X[t + 2 * T], tw.r2a);
-            b0 = X[t + T]; b1 = cmul(X[t + 3 * T], tw.r2b);
+#pragma unroll
+            for (int c = 0; c < 2 * NB; c++) {
+                const int j = t + c * LPT;
+                const double2 a0 = X[j], a1 = cmul(X[j + L / 2], tw.r2[c]);
+                lo[c] = cadd(a0, a1); hi[c] = csub(a0, a1);
+            }
         }
         if (TO_LDS) {
-            pass_sync<LOGL>();
-            if (active) { X[t] = cadd(a0, a1); X[t + Ns] = csub(a0, a1); X[t + T] = cadd(b0, b1); X[t + T + Ns] = csub(b0, b1); }
-            pass_sync<LOGL>();
+            wave_sync();
+            if (active) {
+#pragma unroll
+                for (int c = 0; c < 2 * NB; c++) { X[t + c * LPT] = lo[c]; X[t + c * LPT + L / 2] = hi[c]; }
+            }
+            wave_sync();
         } else if (active) {
-            last(t, cadd(a0, a1)); last(t + Ns, csub(a0, a1));
-            last(t + T, cadd(b0, b1)); last(t + T + Ns, csub(b0, b1));
+#pragma unroll
+            for (int c = 0; c < 2 * NB; c++) { last(t + c * LPT, lo[c]); last(t + c * LPT + L / 2, hi[c]); }
         }
     }
 }
@@ -146,7 +166,7 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw
 // ------------------------------------------------------------------------------------------------ inverse
 // The output planes are `physical` or the node-space array G: value slot fp64, derivative slots ST (Planes, sx_internal.hpp)
 template <int LOGL, int COPYOUT, bool NODE, class ST>
-__global__ void __launch_bounds__(512, 4)
+__global__ void __launch_bounds__(512, LOGL <= 8 ? 4 : 2)      // waves per SIMD: at L = 512 one workgroup per CU (2 x 64 KB of LDS, 4 wavenumbers per lane)
 k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,
@@ -154,7 +174,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                  int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz) {
     // NODE: the "rings" are radial NODES (uniform ring tables only): one Az row per unit, no radial combination;
     // the output is the node-space array G that the equation-set kernel combines with the basis weights itself.
-    constexpr int L = 1 << LOGL, T = L / 4;
+    constexpr int L = 1 << LOGL, T = FftCfg<LOGL>::LPT, NK = FftCfg<LOGL>::NK;
     constexpr int FZC = FftCfg<LOGL>::FZC, FNP = FftCfg<LOGL>::FNP, LOGZ = FftCfg<LOGL>::LOGZ, SKEW = FftCfg<LOGL>::SKEW;
     extern __shared__ double2 smf[];
     FFT_STAMP(0);
@@ -178,10 +198,17 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int mask = slotmask[v];
-    const int k1 = t, k2 = t + T;                                  // this lane's two wavenumbers (k2 < L/2)
-    const bool in1 = k1 <= km, in2 = k2 <= km;
-    const int kc1 = min(k1, K2 / 2 - 1), kc2 = min(k2, K2 / 2 - 1);   // in-row addresses for lanes beyond the truncation (their values are dropped)
-    double2 ph1 = make_double2(1.0, 0.0), ph2 = ph1;               // node tables carry no phase offset
+    // this lane's wavenumbers kq[q] = t + q T < L / 2 (two of them, four at L = 512)
+    int kq[NK], kcq[NK];
+    bool inq[NK];
+    double2 phq[NK];                                               // node tables carry no phase offset
+#pragma unroll
+    for (int q = 0; q < NK; q++) {
+        kq[q] = t + q * T;
+        inq[q] = kq[q] <= km;
+        kcq[q] = min(kq[q], K2 / 2 - 1);      // in-row address for lanes beyond the truncation (their values are dropped)
+        phq[q] = make_double2(1.0, 0.0);
+    }
     const bool pair_ok = ((nz & 1) == 0);                          // (z, z+1) pairs are 16-byte aligned
 
     // groups of output slots that share one radial combination: (sz, d) = (0,0): u, l, ll; (0,1): r; (0,2): rr;
@@ -194,40 +221,49 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
         const int sl1 = grp == 0 ? s_l : -1, sl2 = grp == 0 ? s_ll : -1;
         const bool n0 = sl0 >= 0 && ((mask >> sl0) & 1), n1 = sl1 >= 0 && ((mask >> sl1) & 1), n2 = sl2 >= 0 && ((mask >> sl2) & 1);
         if (!n0 && !n1 && !n2) continue;
-        double2 a1 = make_double2(0.0, 0.0), b1 = a1, a2 = a1, b2 = a1;
+        double2 aq[NK], bq[NK];
         {
             constexpr int R = NODE ? 1 : 4;                // radial rows combined per coefficient
             const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
             const double *a0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + (active ? za : 0))) * K2;
             const double *b0 = a0 + ((active && hasb) ? K2 : 0);
-            // every load of the group first (no branches: lanes beyond the truncation read a valid address and drop the value) ...
-            double2 x1[R], y1[R], x2[R], y2[R];
+            // two wavenumbers at a time: every load of the pair first (no branches: lanes beyond the truncation read a valid
+            // address and drop the value) ...
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                x1[r] = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * kc1);
-                y1[r] = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * kc1);
-                x2[r] = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * kc2);
-                y2[r] = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * kc2);
-            }
-            if (!setup_done) {                             // ... then, once, the twiddles and phase factors behind them
-                asm volatile("" ::: "memory");
-                int tt = t;
-                asm volatile("" : "+v"(tt));               // opaque copy: the table addresses are formed HERE (hoisted out of the
-                                                           // group loop they were spilled, and every reload drained the memory counter)
-                tw.template init<+1>(twg, tt);
-                if (!NODE) { if (in1) ph1 = phr[tt]; if (in2) ph2 = phr[tt + T]; }
-                asm volatile("" ::: "memory");
-                setup_done = true;
-            }
+            for (int q0 = 0; q0 < NK; q0 += 2) {
+                double2 x1[R], y1[R], x2[R], y2[R];
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const double fr = pf[r];
-                if (in1) { a1.x += fr * x1[r].x; a1.y += fr * x1[r].y; b1.x += fr * y1[r].x; b1.y += fr * y1[r].y; }
-                if (in2) { a2.x += fr * x2[r].x; a2.y += fr * x2[r].y; b2.x += fr * y2[r].x; b2.y += fr * y2[r].y; }
+                for (int r = 0; r < R; r++) {
+                    x1[r] = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * kcq[q0]);
+                    y1[r] = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * kcq[q0]);
+                    x2[r] = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * kcq[q0 + 1]);
+                    y2[r] = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * kcq[q0 + 1]);
+                }
+                if (!setup_done) {                             // ... then, once, the twiddles and phase factors behind them
+                    asm volatile("" ::: "memory");
+                    int tt = t;
+                    asm volatile("" : "+v"(tt));               // opaque copy: the table addresses are formed HERE (hoisted out of the
+                                                               // group loop they were spilled, and every reload drained the memory counter)
+                    tw.template init<+1>(twg, tt);
+                    if (!NODE) {
+#pragma unroll
+                        for (int q = 0; q < NK; q++) if (inq[q]) phq[q] = phr[tt + q * T];
+                    }
+                    asm volatile("" ::: "memory");
+                    setup_done = true;
+                }
+                double2 a1 = make_double2(0.0, 0.0), b1 = a1, a2 = a1, b2 = a1;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const double fr = pf[r];
+                    if (inq[q0]) { a1.x += fr * x1[r].x; a1.y += fr * x1[r].y; b1.x += fr * y1[r].x; b1.y += fr * y1[r].y; }
+                    if (inq[q0 + 1]) { a2.x += fr * x2[r].x; a2.y += fr * x2[r].y; b2.x += fr * y2[r].x; b2.y += fr * y2[r].y; }
+                }
+                if (kq[q0] == 0) { a1.y = 0.0; b1.y = 0.0; }      // block 0 is the real k = 0 coefficient, block 1 is padding
+                if (!hasb) { b1 = make_double2(0.0, 0.0); b2 = b1; }
+                if (!NODE) { a1 = cmul(a1, phq[q0]); b1 = cmul(b1, phq[q0]); a2 = cmul(a2, phq[q0 + 1]); b2 = cmul(b2, phq[q0 + 1]); }
+                aq[q0] = a1; bq[q0] = b1; aq[q0 + 1] = a2; bq[q0 + 1] = b2;
             }
-            if (k1 == 0) { a1.y = 0.0; b1.y = 0.0; }      // block 0 is the real k = 0 coefficient, block 1 is padding
-            if (!hasb) { b1 = make_double2(0.0, 0.0); b2 = b1; }
-            if (!NODE) { a1 = cmul(a1, ph1); b1 = cmul(b1, ph1); a2 = cmul(a2, ph2); b2 = cmul(b2, ph2); }
         }
         if (nslot == 0) FFT_STAMP(1);
         for (int ld = 0; ld < 3; ld++) {
@@ -237,23 +273,23 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
             double2 *X = set + f * (L + SKEW);
             par ^= 1;
             if (active) {
-                double2 c1 = a1, e1 = b1, c2 = a2, e2 = b2;
-                if (ld == 1) {                                     // multiply by ik
-                    c1 = make_double2(-k1 * a1.y, k1 * a1.x); e1 = make_double2(-k1 * b1.y, k1 * b1.x);
-                    c2 = make_double2(-k2 * a2.y, k2 * a2.x); e2 = make_double2(-k2 * b2.y, k2 * b2.x);
-                } else if (ld == 2) {                              // multiply by -k^2
-                    const double q1 = -(double)k1 * k1, q2 = -(double)k2 * k2;
-                    c1.x *= q1; c1.y *= q1; e1.x *= q1; e1.y *= q1;
-                    c2.x *= q2; c2.y *= q2; e2.x *= q2; e2.y *= q2;
+#pragma unroll
+                for (int q = 0; q < NK; q++) {
+                    const int k = kq[q];
+                    double2 c = aq[q], e = bq[q];
+                    if (ld == 1) {                                     // multiply by ik
+                        c = make_double2(-k * aq[q].y, k * aq[q].x); e = make_double2(-k * bq[q].y, k * bq[q].x);
+                    } else if (ld == 2) {                              // multiply by -k^2
+                        const double qq = -(double)k * k;
+                        c.x *= qq; c.y *= qq; e.x *= qq; e.y *= qq;
+                    }
+                    // W = Za + i Zb at bin k, conj(Za) + i conj(Zb) at bin L - k; Nyquist bin is zero
+                    X[k] = make_double2(c.x - e.y, c.y + e.x);
+                    if (k > 0) X[L - k] = make_double2(c.x + e.y, e.x - c.y);
+                    else X[L / 2] = make_double2(0.0, 0.0);
                 }
-                // W = Za + i Zb at bin k, conj(Za) + i conj(Zb) at bin L - k; Nyquist bin is zero
-                X[k1] = make_double2(c1.x - e1.y, c1.y + e1.x);
-                if (k1 > 0) X[L - k1] = make_double2(c1.x + e1.y, e1.x - c1.y);
-                else X[L / 2] = make_double2(0.0, 0.0);
-                X[k2] = make_double2(c2.x - e2.y, c2.y + e2.x);
-                X[L - k2] = make_double2(c2.x + e2.y, e2.x - c2.y);
             }
-            pass_sync<LOGL>();
+            wave_sync();
             if (COPYOUT) {
                 // last pass goes back to LDS, then the whole workgroup writes full 128-byte lines
                 fft_inplace<LOGL, +1, true>(X, tw, t, active);
@@ -302,7 +338,7 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                         o[0] = (ST)y.x; if (hasb) o[1] = (ST)y.y;
                     }
                 });
-                pass_sync<LOGL>();      // the region is rewritten by the next slot
+                wave_sync();      // the region is rewritten by the next slot
             }
         }
     }
@@ -315,7 +351,7 @@ __global__ void __launch_bounds__(512)
 k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const int *__restrict__ kmaxr,
                  const int64_t *__restrict__ pstart, const double2 *__restrict__ twg, const int64_t *__restrict__ phoff,
                  const double2 *__restrict__ ph, int V, int nz, int K2, int64_t N) {
-    constexpr int L = 1 << LOGL, T = L / 4;
+    constexpr int L = 1 << LOGL, T = FftCfg<LOGL>::LPT, PPT = L / T;       // lanes per transform; staged pairs per thread
     constexpr int FZC = FftCfg<LOGL>::FZC, FNP = FftCfg<LOGL>::FNP, LOGZ = FftCfg<LOGL>::LOGZ, SKEW = FftCfg<LOGL>::SKEW;
     extern __shared__ double2 smf[];
     const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * FZC;
@@ -332,21 +368,21 @@ k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     // stage the [ring point][FZC levels] tile: the (2 zp, 2 zp + 1) level pair of a point is one 16-byte load and one
     // LDS element of transform zp
     if ((nz & 1) == 0 && (int)blockDim.x == FNP * T) {
-        // the workgroup has FNP * L / 4 threads, the tile FNP * L pairs: exactly 4 per thread.  All four loads are issued before
-        // the first LDS write (rolled, every iteration was a load -> wait -> write round trip to HBM: four in a row)
+        // the workgroup has FNP * T threads, the tile FNP * L pairs: exactly PPT = L / T per thread (4; 8 at L = 512).  All of
+        // them are issued before the first LDS write (rolled, every iteration was a load -> wait -> write round trip to HBM)
         typedef double dv2 __attribute__((ext_vector_type(2)));
         const int zp = tid & (FNP - 1);
-        double2 val[4];
+        double2 val[PPT];
         if (zc == FZC) {                                   // full chunk (wave-uniform): straight-line loads
-            dv2 t2[4];
+            dv2 t2[PPT];
 #pragma unroll
-            for (int i = 0; i < 4; i++)
+            for (int i = 0; i < PPT; i++)
                 t2[i] = __builtin_nontemporal_load(reinterpret_cast<const dv2 *>(x + (int64_t)((tid + i * FNP * T) >> (LOGZ - 1)) * nz + 2 * zp));
 #pragma unroll
-            for (int i = 0; i < 4; i++) val[i] = make_double2(t2[i].x, t2[i].y);
+            for (int i = 0; i < PPT; i++) val[i] = make_double2(t2[i].x, t2[i].y);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < PPT; i++) {
                 const int l = (tid + i * FNP * T) >> (LOGZ - 1);
                 val[i] = make_double2(0.0, 0.0);
                 if (2 * zp + 1 < zc) {
@@ -358,7 +394,7 @@ k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const 
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) smf[zp * (L + SKEW) + ((tid + i * FNP * T) >> (LOGZ - 1))] = val[i];
+        for (int i = 0; i < PPT; i++) smf[zp * (L + SKEW) + ((tid + i * FNP * T) >> (LOGZ - 1))] = val[i];
     } else {
         double *ba = (double *)smf;
         for (int o = tid; o < L * FZC; o += blockDim.x) {
@@ -400,12 +436,12 @@ static int ilog2(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
 
 bool fft_path_ok(const sx_handle *h) {
     const int L = h->uniform_L;
-    return h->has_l && L >= 16 && L <= 512 && (L & (L - 1)) == 0;   // one transform = L/4 lanes: one wave, or two for L = 512
+    return h->has_l && L >= 16 && L <= 512 && (L & (L - 1)) == 0;   // one transform = min(L/4, 64) lanes of one wave
 }
 
-static int fft_fzc(int L) { return L <= 256 ? 16 : 8; }
+static int fft_fzc(int) { return 16; }
 static size_t fft_lds(int L, int sets = 1) { return sizeof(double2) * (size_t)sets * (fft_fzc(L) / 2) * (L + (L <= 256 ? 2 : 0)); }
-static int fft_threads(int L) { return std::max(64, (fft_fzc(L) / 2) * (L / 4)); }
+static int fft_threads(int L) { return std::max(64, (fft_fzc(L) / 2) * std::min(L / 4, 64)); }       // FNP transforms x LPT lanes
 
 struct InvTarget {          // where an inverse ring launch writes and which unit tables it uses
     double *out;            // physical [slot][v][N] or node-space G [slot][v][NG]
@@ -422,10 +458,15 @@ static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, con
     const int L = 1 << LOGL;
     dim3 g((h->nz + fft_fzc(L) - 1) / fft_fzc(L), h->V, tg.n_units);
 #define INV_LAUNCH(NODE, ST)                                                                                                         \
-    hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az,                  \
-                       planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart,     \
-                       h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],            \
-                       h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6])
+    do {                                                                                                                             \
+        if (fft_lds(L, 2) > 65536)                                                                                                   \
+            HIPCHK2(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rl_inverse_fft<LOGL, 1, NODE, ST>),                         \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds(L, 2)));                           \
+        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az,              \
+                           planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart,                                            \
+                           h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],        \
+                           h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);                                  \
+    } while (0)
     if (h->f32) { if (tg.node_mode) INV_LAUNCH(true, float); else INV_LAUNCH(false, float); }
     else { if (tg.node_mode) INV_LAUNCH(true, double); else INV_LAUNCH(false, double); }
 #undef INV_LAUNCH
