@@ -590,6 +590,7 @@ int sx_destroy(sx_handle *h) {
     phases_dump();
     fft_phases_dump();
     sbw_phases_dump();
+    dft_phases_dump();
 #endif
     comm_release(h);
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }

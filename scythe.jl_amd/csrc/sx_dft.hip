@@ -19,7 +19,9 @@
 // vertical level.
 #include "sx_internal.hpp"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace sx {
 
@@ -30,6 +32,16 @@ namespace sx {
     } while (0)
 
 typedef double dft_d4 __attribute__((ext_vector_type(4)));
+
+// phase stamps of the diagnostic build (-DSX_PHASES): per workgroup of k_rl_inverse_dft, as seen by wave 0:
+// [0] total cycles, [1] staging of the coefficient sets (loads .. barrier), [2] matrix-core loops, [3] result stores,
+// [4] row tiles done, [5] ring length, [6] matrix-core instructions issued, [7] total in 100 MHz real-time ticks
+#ifdef SX_PHASES
+__device__ long long *g_dft_dbg = nullptr;
+#define DFT_NOW() ((long long)__builtin_readcyclecounter())
+#else
+#define DFT_NOW() 0ll
+#endif
 
 constexpr int DZC = 16;       // levels per workgroup = MFMA N
 constexpr int CST = 17;       // row stride (doubles) of the LDS tiles: 4 consecutive rows land in different banks
@@ -68,6 +80,11 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    [[maybe_unused]] const long long dbg_t0 = DFT_NOW();
+    [[maybe_unused]] long long dbg_stage = 0, dbg_mm = 0, dbg_st = 0, dbg_tiles = 0, dbg_nmfma = 0;
+#ifdef SX_PHASES
+    const long long dbg_r0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
 
     for (int q = 0; q < 5; q++) {
@@ -80,6 +97,7 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
         if (!need0 && !needl && !needll) continue;
         const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
         const double f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
+        [[maybe_unused]] const long long dbg_t1 = DFT_NOW();
         __syncthreads();                                        // the previous set has been consumed (and twl is complete)
         {
             // thread -> (level zz, wavenumber kq + 32 b): the 4 radial rows of a wavenumber come as 16-byte (Re, Im) pairs, and
@@ -119,6 +137,7 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
             }
         }
         __syncthreads();
+        dbg_stage += DFT_NOW() - dbg_t1;
 
         const int i = lane & 15, kk = lane >> 4;
         // Quarter-wave form: with L a multiple of 4, cos(k theta (L/2 - l)) = (-1)^k cos(k theta l) and
@@ -130,6 +149,9 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
         const int Lq = L / 4;
         for (int mt = wave; mt * 16 <= Lq; mt += nw) {
             const int lrow = min(mt * 16 + i, Lq);                 // A operand: this lane's ring point
+            [[maybe_unused]] const long long dbg_t2 = DFT_NOW();
+            dbg_tiles++;
+            dbg_nmfma += (long long)(((km / 2 + 1 + 3) >> 2) + (km >= 1 ? (((km - 1) / 2 + 1 + 3) >> 2) : 0)) * 2 * ((need0 ? 1 : 0) + (needl ? 1 : 0) + (needll ? 1 : 0));
             dft_d4 z4 = {0.0, 0.0, 0.0, 0.0};
             dft_d4 pu[2] = {z4, z4}, qu[2] = {z4, z4}, pl[2] = {z4, z4}, ql[2] = {z4, z4}, pll[2] = {z4, z4}, qll[2] = {z4, z4};
 #pragma unroll
@@ -164,6 +186,11 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                 }
             }
             // D tile: lane holds column n = lane & 15 (level), rows (lane >> 4) + 4 r (points l of the quarter ring)
+#ifdef SX_PHASES
+            asm volatile("s_nop 0" : "+v"(pu[0]), "+v"(qu[0]), "+v"(pu[1]), "+v"(qu[1]));      // the accumulators are final here
+#endif
+            [[maybe_unused]] const long long dbg_t3 = DFT_NOW();
+            dbg_mm += dbg_t3 - dbg_t2;
             if (i < zc) {
                 auto put = [&](int slot, int64_t pt, double val) {
                     if (slot == 0) phys.val[(int64_t)v * N + pt] = val;
@@ -187,8 +214,16 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                     if (needll) put4(s_ll, lo, pll[0][r], pll[1][r], qll[0][r], qll[1][r]);
                 }
             }
+            dbg_st += DFT_NOW() - dbg_t3;
         }
     }
+#ifdef SX_PHASES
+    if (tid == 0 && g_dft_dbg) {
+        long long *o = g_dft_dbg + (((int64_t)ring * gridDim.y + v) * gridDim.x + blockIdx.x) * 8;
+        o[0] = DFT_NOW() - dbg_t0; o[1] = dbg_stage; o[2] = dbg_mm; o[3] = dbg_st; o[4] = dbg_tiles; o[5] = L; o[6] = dbg_nmfma;
+        o[7] = (long long)__builtin_amdgcn_s_memrealtime() - dbg_r0;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ inverse, RL grids
@@ -457,9 +492,33 @@ static void launch_rl_inverse_dft_planes(sx_handle *h, bool full) {
     }, 2);
 }
 
+#ifdef SX_PHASES
+static long long *g_dft_buf = nullptr;
+static int64_t g_dft_n = 0;
+void dft_phases_dump() {
+    const char *path = getenv("SX_DFT_PHASES_OUT");
+    if (!path || !g_dft_buf) return;
+    std::vector<long long> hst((size_t)g_dft_n * 8);
+    hipDeviceSynchronize();
+    hipMemcpy(hst.data(), g_dft_buf, sizeof(long long) * hst.size(), hipMemcpyDeviceToHost);
+    FILE *f = fopen(path, "wb");
+    if (f) { fwrite(hst.data(), sizeof(long long), hst.size(), f); fclose(f); }
+}
+#else
+void dft_phases_dump() {}
+#endif
+
 void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
     const int id = timer_id(h, "k_rl_inverse");
     timer_begin(h, id);
+#ifdef SX_PHASES
+    if (!g_dft_buf && !dft_planes(h)) {
+        g_dft_n = (int64_t)((h->nz + DZC - 1) / DZC) * h->V * h->nrings;
+        hipMalloc(&g_dft_buf, sizeof(long long) * g_dft_n * 8);
+        hipMemset(g_dft_buf, 0, sizeof(long long) * g_dft_n * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_dft_dbg), &g_dft_buf, sizeof(g_dft_buf));
+    }
+#endif
     if (dft_planes(h)) {
         launch_rl_inverse_dft_planes(h, d_mask == h->d_mask_full);
         timer_end(h);

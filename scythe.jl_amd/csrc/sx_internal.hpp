@@ -193,5 +193,6 @@ void comm_release(sx_handle *h);
 void phases_dump();
 void fft_phases_dump();
 void sbw_phases_dump();
+void dft_phases_dump();
 #endif
 }  // namespace sx
