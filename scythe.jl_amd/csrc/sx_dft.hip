@@ -28,7 +28,7 @@ namespace sx {
 #define HIPCHK3(x)                                                                                  \
     do {                                                                                            \
         hipError_t e_ = (x);                                                                        \
-        if (e_ != hipSuccess) set_error(std::string(#x) + ": " + hipGetErrorString(e_));            \
+        if (e_ != hipSuccess) set_error(std::string(#x) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
     } while (0)
 
 typedef double dft_d4 __attribute__((ext_vector_type(4)));

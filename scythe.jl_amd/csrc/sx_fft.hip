@@ -19,7 +19,7 @@ namespace sx {
 #define HIPCHK2(x)                                                                                  \
     do {                                                                                            \
         hipError_t e_ = (x);                                                                        \
-        if (e_ != hipSuccess) set_error(std::string(#x) + ": " + hipGetErrorString(e_));            \
+        if (e_ != hipSuccess) set_error(std::string(#x) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
     } while (0)
 
 // z levels per workgroup (FZC) and complex transforms per slot and workgroup (FNP = FZC / 2).  A transform of length L is

@@ -19,7 +19,7 @@ namespace sx {
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
         hipError_t e_ = (x);                                                                        \
-        if (e_ != hipSuccess) set_error(std::string(#x) + ": " + hipGetErrorString(e_));            \
+        if (e_ != hipSuccess) set_error(std::string(#x) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
     } while (0)
 
 constexpr int ZC = 16;   // z-levels per workgroup in the ring kernels: 16 * 8 B = one 128-B line per (ring point)
@@ -1937,6 +1937,10 @@ void launch_fl_forward(sx_handle *h) {
     timer_begin(h, id);
     const int xstride = h->L_max | 1;
     const size_t lds = sizeof(double) * ZC * xstride;
+    if (lds > 64 * 1024) {       // the scalar kernel stages a whole ring; longer native rings need the matrix-core DFT (kmax <= 319)
+        set_error("azimuthal forward transform: rings of " + std::to_string(h->L_max) + " points are outside every transform path (uniform power-of-two tables up to 512, native rings with kmax <= 319, scalar up to 511 points)");
+        return;
+    }
     dim3 g((h->nz + ZC - 1) / ZC, h->V, h->nrings);
     hipLaunchKernelGGL(k_fl_forward, g, dim3(256), lds, h->stream, h->d_np1, h->d_Fl, h->d_L, h->d_kmax, h->d_pstart,
                        h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N, h->has_l, xstride);
