@@ -176,3 +176,27 @@ def test_output_time_tag_is_julias_string_of_round_t_2():
         assert j(x) == want, (x, j(x), want)
     assert tag(3 * 0.1) == "0.3" and tag(100.0) == "100.0" and tag(0.0) == "0.0" and tag(86400.004) == "86400.0"
     assert tag(2000 * 0.05) == "100.0"          # the notebook's final file: physical_out_100.0.csv
+
+
+def test_partitioned_interface_only_patch_solve_equals_the_patch_solve():
+    """Prototype of the SPIKE-type B -> A solve for radial tiles (scythe_jl_amd.partitioned_solve): every tile
+    solves its own rows, 6 interface unknowns per tile boundary are exchanged - against the one-patch Cholesky solve of the
+    reference's matrix (src/semiimplicit.jl:285 via Springsteel SAtransform), all radial boundary-condition classes."""
+    from oracle import oracle_np as O
+    from scythe_jl_amd.partitioned_solve import PartitionedBandedSolve
+    import scythe_jl_amd as S
+    rng = np.random.default_rng(5)
+    for bcl, bcr in (("R0", "R0"), ("R1T0", "R1T1"), ("R1T1", "R0"), ("R2T10", "R1T0"), ("R3", "R0"), ("PERIODIC", "PERIODIC")):
+        sp = O.Spline1D(0.0, 3.0e5, 171, bcl=bcl, bcr=bcr)
+        n = sp.PQ.shape[0]
+        b = sp.G @ rng.standard_normal((sp.bdim, 7))
+        ref = np.linalg.solve(sp.PQ, b)
+        for N in (2, 4, 8):
+            lay = S.PatchLayout(S.GridParameters(geometry="R", xmin=0.0, xmax=3.0e5, num_cells=171, vars={"u": 1}), N)
+            bounds = [0] + [min(n - 1, c) for c in lay.cell0[1:]] + [n]
+            ps = PartitionedBandedSolve(sp.PQ, bounds)
+            got = ps.solve(b)
+            assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), (bcl, bcr, N, np.abs(got - ref).max() / np.abs(ref).max())
+            wrap = 6 if bcl == "PERIODIC" else 0
+            assert len(ps.I) == 6 * (N - 1) + wrap, (bcl, N, len(ps.I))
+            assert max(ps.sends) <= 6 and max(ps.needs) <= 6 + wrap
