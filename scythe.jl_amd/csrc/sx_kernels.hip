@@ -453,15 +453,21 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
 // v_mfma_f64_16x16x4_f64 per tile with B = the node's [level][block] tile in LDS (row stride 80 doubles: the 4 levels a
 // K-step reads fall in disjoint bank halves).  One 512-thread workgroup per CU; the grid is one round.
 // Summation order differs from k_sbw / k_sbz (K in blocks of 4): results agree to rounding, not bitwise.
-template <int NZ>
+// BW = wavenumber blocks per workgroup: 64 (zDim 32 / 64), or 32 for zDim 128, where the operator fragments (6 row tiles x
+// 32 K steps = 96 KB) and the node tile (128 levels x 32 blocks) have to share the 160 KB; then wave w owns column tile
+// w & 1 and the row tiles (w >> 1), (w >> 1) + 4.
+template <int NZ, int BW = 64>
 __global__ void __launch_bounds__(512, 2)
 k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *__restrict__ phi, const double *__restrict__ wq,
            const double *__restrict__ CB, int ncells, int V, int Zb, int K2, int64_t C, int cps) {
-    constexpr int ZPT = NZ / 8, KS = NZ / 4, LS = 80;
+    constexpr int NG = 512 / BW;                      // level groups: thread = (group g, block lb), levels z = g + NG i
+    constexpr int ZPT = NZ / NG, KS = NZ / 4, LS = BW + 16;      // LS: the 4 levels a K step reads fall in disjoint bank halves
+    constexpr int MTMAX = BW == 64 ? 4 : 6;           // row tiles of 16 modes: b_zDim <= 64 / <= 96
     __shared__ double As[NZ * LS];
-    const int lane = threadIdx.x & 63;
-    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = blockIdx.x * 64 + lane;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lb = threadIdx.x & (BW - 1);
+    const int g = BW == 64 ? wv : (int)(threadIdx.x / BW);
+    const int blk = blockIdx.x * BW + lb;
     const int v = blockIdx.y;
     const bool ok = blk < K2;
     const int ca = blockIdx.z * cps, cb = min(ca + cps, ncells);
@@ -471,17 +477,21 @@ k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *
     const double *base = Fl + ((int64_t)v * NZ + g) * K2 + (ok ? blk : 0);
     // operator fragments: A[m][k] = CB[m][k], lane supplies m = 16 mt + (lane & 15), k = 4 js + (lane >> 4)
     const int MT = (Zb + 15) / 16, mhalf = (MT + 1) / 2;
-    const int mt0 = g < 4 ? 0 : mhalf, nmt = g < 4 ? mhalf : MT - mhalf;      // this wave's row tiles [mt0, mt0 + nmt), nmt <= 2
-    const int nt = g & 3, n = lane & 15, kk = lane >> 4;
+    // this wave's column tile nt and row tiles mt0, mt1 (nmt of them)
+    const int nt = BW == 64 ? (wv & 3) : (wv & 1);
+    const int mt0 = BW == 64 ? (wv < 4 ? 0 : mhalf) : (wv >> 1);
+    const int mt1 = BW == 64 ? mt0 + 1 : mt0 + 4;
+    const int nmt = BW == 64 ? (wv < 4 ? mhalf : MT - mhalf) : (mt0 >= MT ? 0 : mt1 < MT ? 2 : 1);
+    const int n = lane & 15, kk = lane >> 4;
     // (kept in LDS in fragment order [row tile][K step][lane]: a conflict-free 8-byte read per MFMA; in registers the two
     // tiles' 64 VGPRs pushed the kernel into spills)
-    __shared__ double Af[4 * KS * 64];
+    __shared__ double Af[MTMAX * KS * 64];
     for (int e = threadIdx.x; e < MT * KS * 64; e += blockDim.x) {
         const int l = e & 63, js = (e >> 6) % KS, mt = e / (64 * KS);
         const int m = mt * 16 + (l & 15);
         Af[e] = (m < Zb) ? CB[(int64_t)m * NZ + 4 * js + (l >> 4)] : 0.0;
     }
-    const double *af0 = Af + (size_t)mt0 * KS * 64 + lane, *af1 = af0 + (nmt > 1 ? KS * 64 : 0);
+    const double *af0 = Af + (size_t)(nmt > 0 ? mt0 : 0) * KS * 64 + lane, *af1 = Af + (size_t)(nmt > 1 ? mt1 : 0) * KS * 64 + lane;
     double acc[4][ZPT];
 #pragma unroll
     for (int q = 0; q < 4; q++)
@@ -494,7 +504,7 @@ k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *
         for (int mu = 0; mu < MUBAR; mu++) {
             const double *src = base + (int64_t)(c * MUBAR + mu) * plane;
 #pragma unroll
-            for (int i = 0; i < ZPT; i++) xn[mu][i] = __builtin_nontemporal_load(src + (int64_t)(8 * i) * K2);
+            for (int i = 0; i < ZPT; i++) xn[mu][i] = __builtin_nontemporal_load(src + (int64_t)(NG * i) * K2);
         }
     };
     fetch(cstart);
@@ -529,24 +539,26 @@ k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *
                 __syncthreads();                // the previous node's tile has been consumed
                 SBW_LAP(1);
 #pragma unroll
-                for (int i = 0; i < ZPT; i++) As[(g + 8 * i) * LS + lane] = acc[u][i];
+                for (int i = 0; i < ZPT; i++) As[(g + NG * i) * LS + lb] = acc[u][i];
                 __syncthreads();
                 SBW_LAP(2);
                 colmat_d4 o0 = {0.0, 0.0, 0.0, 0.0}, o1 = o0;
                 const double *xb = As + kk * LS + nt * 16 + n;
+                if (nmt > 0) {
 #pragma unroll
-                for (int js = 0; js < KS; js++) {
-                    const double b = xb[(4 * js) * LS];
-                    o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[js * 64], b, o0, 0, 0, 0);
-                    if (nmt > 1) o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[js * 64], b, o1, 0, 0, 0);
+                    for (int js = 0; js < KS; js++) {
+                        const double b = xb[(4 * js) * LS];
+                        o0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[js * 64], b, o0, 0, 0, 0);
+                        if (nmt > 1) o1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[js * 64], b, o1, 0, 0, 0);
+                    }
                 }
                 // D[row = kk + 4 r][col = n]
-                const int col = blockIdx.x * 64 + nt * 16 + n;
+                const int col = blockIdx.x * BW + nt * 16 + n;
                 if (col < K2) {
                     double *dst = B + (int64_t)c * C + (int64_t)v * Zb * K2 + col;
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int m0 = mt0 * 16 + kk + 4 * r, m1 = m0 + 16;
+                        const int m0 = mt0 * 16 + kk + 4 * r, m1 = mt1 * 16 + kk + 4 * r;
                         if (nmt > 0 && m0 < Zb) dst[(int64_t)m0 * K2] = o0[r];
                         if (nmt > 1 && m1 < Zb) dst[(int64_t)m1 * K2] = o1[r];
                     }
@@ -1957,14 +1969,16 @@ void launch_sb(sx_handle *h) {
             // CU) the grid is ONE round of at most 256 workgroups; without it (zDim 128: 16 values per thread and ring leave no
             // registers for a second set; or SX_SBW_PF=0) about 1.5 workgroups per CU as before.  On large tiles never fewer
             // than 6 cells so that the warm-up stays below half of the reads
-            const int groups = ((h->K2 + 63) / 64) * h->V;
-            const bool mf = h->sbw_mfma && h->nz <= 64 && h->Zb <= 64;      // matrix-core contraction + prefetch (k_sbw_mfma)
+            const bool mf = h->sbw_mfma && (h->nz <= 64 ? h->Zb <= 64 : h->Zb <= 96);      // matrix-core contraction + prefetch (k_sbw_mfma)
+            const int bw = (mf && h->nz == 128) ? 32 : 64;                   // wavenumber blocks per workgroup
+            const int groups = ((h->K2 + bw - 1) / bw) * h->V;
             const bool pf = (h->sbw_prefetch && h->nz <= 64) || mf;
-            const int nseg = std::max(1, (pf || h->nz == 128 ? 256 : 384) / groups);
+            static const int seg_env = getenv("SX_SBW_SEG") ? atoi(getenv("SX_SBW_SEG")) : 0;      // experiments: segments per (block group, variable)
+            const int nseg = seg_env > 0 ? seg_env : std::max(1, (mf && h->nz == 128 ? 512 : pf || h->nz == 128 ? 256 : 384) / groups);
             // small tiles (multi-GPU strong scaling): the kernel is then one workgroup's latency chain, which is proportional
             // to the cells it walks, so short segments (down to 2 cells + 3 warm-up) beat the saved re-reads
             const int cps = std::max(h->ncells <= 64 ? 2 : 6, (h->ncells + nseg - 1) / nseg);
-            dim3 gw((h->K2 + 63) / 64, h->V, (h->ncells + cps - 1) / cps);
+            dim3 gw((h->K2 + bw - 1) / bw, h->V, (h->ncells + cps - 1) / cps);
 #ifdef SX_PHASES
             if (!g_sbw_buf) {
                 g_sbw_n = (int64_t)gw.x * gw.y * gw.z;
@@ -1974,7 +1988,7 @@ void launch_sb(sx_handle *h) {
             }
 #endif
             auto kern = h->nz == 64 ? (pf ? k_sbw<64, true> : k_sbw<64, false>) : h->nz == 32 ? (pf ? k_sbw<32, true> : k_sbw<32, false>) : k_sbw<128, false>;
-            if (mf) kern = h->nz == 64 ? k_sbw_mfma<64> : k_sbw_mfma<32>;
+            if (mf) kern = h->nz == 64 ? k_sbw_mfma<64> : h->nz == 32 ? k_sbw_mfma<32> : k_sbw_mfma<128, 32>;
             hipLaunchKernelGGL(kern, gw, dim3(512), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->d_CB, h->ncells,
                                h->V, h->Zb, h->K2, h->C, cps);
             HIPCHK(hipGetLastError());
