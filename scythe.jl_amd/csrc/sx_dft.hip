@@ -425,6 +425,111 @@ k_fl_forward_dft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     }
 }
 
+// Quarter-wave form of the forward transform (grids with a vertical dimension; every ring length is a multiple of 4):
+// with theta = 2 pi / L the four points l, L - l, L/2 - l, L/2 + l share cos / sin(k theta l) up to signs that depend on
+// the parity of k only, so the ring is folded onto l = 0 .. L/4 once per parity while staging,
+//   even k:  Ce = a + b + c + d,  Se = a - b - c + d        a = x[l], b = x[L - l], c = x[L/2 - l], d = x[L/2 + l]
+//   odd k:   Co = a + b - c - d,  So = a - b + c - d        (l = 0: a +- x[L/2], no sine part;  l = L/4: a +- b in Ce / So)
+//   sr[k] = sum_l C[l] cos(k theta l),   si[k] = -sum_l S[l] sin(k theta l)
+// - half the matrix-core work of the half-ring form.  Wave w transforms wavenumbers of parity w & 1 (tiles of 16: k = 2 (16 t
+// + n) + parity, t = (w >> 1) + 4 q), so ONE fetch of the folded values feeds all its tiles (6 MFMAs per fetch with three
+// tiles; the f64 matrix cores sustain 65 TFLOP/s that way against 50 at 2 per fetch, profiles/micro/mfma_f64_rate.hip).
+constexpr int LCQ = 64;       // quarter-ring points per staged chunk
+
+__global__ void __launch_bounds__(512)
+k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, const int *__restrict__ Lr,
+                   const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
+                   const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V, int nz,
+                   int K2, int64_t N, int ring0, int lcap) {
+    extern __shared__ double sm[];
+    const int ring = ring0 + blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * DZC;
+    const int zc = min(DZC, nz - z0);
+    const int L = Lr[ring], km = kmaxr[ring], Lh = L / 2, Lq = L / 4;
+    double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]
+    double *F = sm + 2 * (size_t)lcap;                          // [parity][cosine / sine part][LCQ][CST]
+    const double2 *phr = ph + phoff[ring];
+    const int64_t p0 = pstart[ring];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
+    const int n = lane & 15, kk = lane >> 4;
+    const int par = wave & 1, tq = wave >> 1;                       // this wave's parity and first tile
+    const int nk = km >= par ? (km - par) / 2 + 1 : 0;              // wavenumbers of this parity
+    const int ntile = (nk + 15) / 16;
+    dft_d4 ac[NTW], as[NTW];
+    int kq[NTW], fourk[NTW];
+#pragma unroll
+    for (int q = 0; q < NTW; q++) {
+        ac[q] = dft_d4{0.0, 0.0, 0.0, 0.0}; as[q] = ac[q];
+        kq[q] = min(2 * (16 * (tq + 4 * q) + n) + par, km);         // this lane's B column (clamped: columns past km are dropped)
+        fourk[q] = (int)(((int64_t)4 * kq[q]) % L);
+    }
+    const double *x = np1 + (int64_t)v * N + p0 * nz + z0;
+    const double *Fc = F + (size_t)(2 * par) * LCQ * CST, *Fs = Fc + (size_t)LCQ * CST;
+
+    for (int lc = 0; lc <= Lq; lc += LCQ) {
+        __syncthreads();
+        for (int o = tid; o < LCQ * DZC; o += blockDim.x) {
+            const int zz = o & (DZC - 1), r = o >> 4, l = lc + r;
+            double ce = 0.0, se = 0.0, co = 0.0, so = 0.0;
+            if (zz < zc && l <= Lq) {
+                const double a = x[(int64_t)l * nz + zz];
+                if (l == 0) {
+                    const double c = x[(int64_t)Lh * nz + zz];
+                    ce = a + c; co = a - c;
+                } else if (l == Lq) {
+                    const double b = x[(int64_t)(L - l) * nz + zz];
+                    ce = a + b; so = a - b;
+                } else {
+                    const double b = x[(int64_t)(L - l) * nz + zz], c = x[(int64_t)(Lh - l) * nz + zz], d = x[(int64_t)(Lh + l) * nz + zz];
+                    const double ab = a + b, cd = c + d, amb = a - b, dmc = d - c;
+                    ce = ab + cd; co = ab - cd; se = amb + dmc; so = amb - dmc;
+                }
+            }
+            F[(0 * LCQ + r) * CST + zz] = ce;
+            F[(1 * LCQ + r) * CST + zz] = se;
+            F[(2 * LCQ + r) * CST + zz] = co;
+            F[(3 * LCQ + r) * CST + zz] = so;
+        }
+        __syncthreads();
+        if (tq * 16 >= nk) continue;                                // nothing for this wave (uniform)
+        const int ln4 = (min(LCQ, Lq + 1 - lc) + 3) & ~3;           // rows past Lq are staged as zeros
+        int m[NTW];
+#pragma unroll
+        for (int q = 0; q < NTW; q++) m[q] = (int)(((int64_t)kq[q] * (lc + kk)) % L);
+        for (int ls = 0; ls < ln4; ls += 4) {
+            const double xc = Fc[(ls + kk) * CST + n], xs = Fs[(ls + kk) * CST + n];
+#pragma unroll
+            for (int q = 0; q < NTW; q++) {
+                if (tq + 4 * q >= ntile) continue;                  // uniform
+                const double2 t = twl[m[q]];
+                ac[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xc, t.x, ac[q], 0, 0, 0);
+                as[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, t.y, as[q], 0, 0, 0);
+                m[q] += fourk[q];
+                if (m[q] >= L) m[q] -= L;
+            }
+        }
+    }
+    // D tile: lane holds column n (wavenumber of the tile), rows kk + 4 r.  sr = ac, si = -as; phase reference e^{-i k off}
+    const double inv = 1.0 / L;
+#pragma unroll
+    for (int q = 0; q < NTW; q++) {
+        const int k = 2 * (16 * (tq + 4 * q) + n) + par;
+        if (tq + 4 * q >= ntile || k > km) continue;
+        const double2 w = phr[k];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int zz = kk + 4 * r;
+            if (zz >= zc) continue;
+            const double sr = ac[q][r], si = -as[q][r];
+            double2 out;
+            if (k == 0) out = make_double2(sr * inv, 0.0);
+            else out = make_double2((sr * w.x + si * w.y) * inv, (si * w.x - sr * w.y) * inv);
+            double *dst = Fl + (((int64_t)ring * V + v) * nz + z0 + zz) * K2 + 2 * k;
+            *reinterpret_cast<double2 *>(dst) = out;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 // grids without a vertical dimension: columns = (variable, plane)
 static bool dft_planes(const sx_handle *h) { return !h->has_z; }
@@ -550,6 +655,19 @@ void launch_fl_forward_dft(sx_handle *h) {
     const int id = timer_id(h, "k_fl_forward");
     timer_begin(h, id);
     const int planes = dft_planes(h) ? 1 : 0;
+    static const bool half = getenv("SX_DFT_HALF") && atoi(getenv("SX_DFT_HALF")) != 0;      // A/B: the half-ring kernel
+    if (!planes && !half) {          // quarter-wave form; 4 waves x NTW tiles x 16 = 192 wavenumbers per parity >= (kmax <= 319) / 2 + 1
+        for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int) {
+            const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * LCQ * CST);
+            dim3 g((h->nz + DZC - 1) / DZC, h->V, nr);
+            HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fl_forward_dft_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_fl_forward_dft_q, g, dim3(512), lds, h->stream, h->d_np1, h->d_Fl, h->d_L, h->d_kmax, h->d_pstart,
+                               h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N, r0, lcap);
+            HIPCHK3(hipGetLastError());
+        }, 4);
+        timer_end(h);
+        return;
+    }
     for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int) {
         const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)2 * LCH * CST);
         // planes: one wavenumber tile per wave, the ring's (kmax + 1) / 16 tiles spread over gridDim.y workgroups of 8 waves
