@@ -1,5 +1,4 @@
 #!/bin/bash
 OUT=$(pwd)/gpurun_out/r02; mkdir -p $OUT
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x -k "native or config4 or ragged" > $OUT/gpu_tests_subset.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/gpu_tests_subset.log
-timeout -k 10 300 python3 profiles/native_timers.py 20 > $OUT/native_timers.json 2>$OUT/native_timers.err; cat $OUT/native_timers.json
-SX_DFT_HALF=1 timeout -k 10 300 python3 profiles/native_timers.py 20 2>/dev/null
+timeout -k 10 300 python3 profiles/native_timers.py 20 > $OUT/native_timers.json 2>$OUT/native_timers.err; cat $OUT/native_timers.json; tail -2 $OUT/native_timers.err
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x -k "native or config4 or ragged or tiles or rz or kat" > $OUT/gpu_tests_subset.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/gpu_tests_subset.log

@@ -1,6 +1,7 @@
 // C ABI of libscythe_hip.so (declared in include/scythe_hip.h).
 #include "sx_internal.hpp"
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -260,7 +261,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->rDim = MUBAR * h->nc; h->b_rDim = h->nc + 3;
     h->uniform_L = h->has_l ? g->ring_uniform_L : 0;
     h->f32 = g->storage_f32 ? 1 : 0;
-    h->overlap = getenv("SX_OVERLAP") && atoi(getenv("SX_OVERLAP")) != 0;
+    h->overlap = getenv("SX_OVERLAP") ? atoi(getenv("SX_OVERLAP")) : 0;
     h->wide = !(getenv("SX_WIDE") && atoi(getenv("SX_WIDE")) == 0);
     h->sbw_prefetch = getenv("SX_SBW_PF") && atoi(getenv("SX_SBW_PF")) != 0;
     h->sbw_mfma = !(getenv("SX_SBW_MFMA") && atoi(getenv("SX_SBW_MFMA")) == 0);
@@ -515,6 +516,25 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         }
         h->hmask_full = full; h->hmask_eq = eq;
         if (!upload(h, &h->d_mask_full, full) || !upload(h, &h->d_mask_eq, eq)) FAIL();
+        if (h->has_z && dft_mfma_ok(h)) {
+            // Work lists of the native-ring DFT kernels: one launch over all rings, workgroups dispatched in order of
+            // decreasing cost (ring length squared x planes of the variable) so that the cheap ones fill the tail;
+            // variables without a requested slot get no workgroup at all.
+            for (int which = 0; which < 3; which++) {
+                std::vector<std::array<int64_t, 3>> it;          // (cost, ring, v)
+                for (int r = 0; r < h->nrings; r++)
+                    for (int v = 0; v < h->V; v++) {
+                        const int planes = which == 2 ? 1 : __builtin_popcount(which == 0 ? eq[v] : full[v]);
+                        if (planes == 0) continue;
+                        it.push_back({(int64_t)h->hL[r] * h->hL[r] * planes, r, v});
+                    }
+                std::stable_sort(it.begin(), it.end(), [](const auto &a, const auto &b) { return a[0] > b[0]; });
+                std::vector<int> flat;
+                for (const auto &e : it) { flat.push_back((int)e[1]); flat.push_back((int)e[2]); }
+                h->n_dft_items[which] = (int)it.size();
+                if (!upload(h, &h->d_dft_items[which], flat)) FAIL();
+            }
+        }
         // node-space ("radial last") inverse: uniform power-of-two rings + the MFMA HRBL kernel
         if (h->eq == SX_EQ_ONEWAY_SW_HRBL && h->V == 6 && fft_path_ok(h) && h->has_z && (h->nz == 64 || h->nz == 32 || h->nz == 128) &&
             !(getenv("SX_NODE_MODE") && atoi(getenv("SX_NODE_MODE")) == 0)) {

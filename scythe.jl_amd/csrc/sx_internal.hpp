@@ -111,6 +111,10 @@ struct sx_handle {
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 0;
+    // native-ring DFT launches (sx_dft.hip): (ring, variable) work items, most expensive first; [0] inverse with the
+    // equation-set slot mask, [1] inverse with every slot, [2] forward
+    int *d_dft_items[3] = {nullptr, nullptr, nullptr};
+    int n_dft_items[3] = {0, 0, 0};
     int sbw_mfma = 1;       // k_sbw_mfma (matrix-core vertical contraction, operator in registers) for zDim 64 / 32 (SX_SBW_MFMA=0: k_sbw)
     int sbw_prefetch = 0;   // k_sbw requests the next cell's ring spectra before contracting the current node (SX_SBW_PF=0: off)
     int wide = 1;    // 16-byte-per-lane loads / stores in the equation-set kernels (SX_WIDE=0: the 8-byte forms, A/B timing)
