@@ -89,56 +89,76 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
 #endif
     for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
 
+    // coefficient sets q: (sz, d) = (0,0) (0,1) (0,2) (1,0) (2,0); only those with a requested slot
+    int qs[5], nq = 0;
     for (int q = 0; q < 5; q++) {
-        // coefficient set q: (sz, d) = (0,0) (0,1) (0,2) (1,0) (2,0)
-        const int sz = q < 3 ? 0 : q - 2, d = q < 3 ? q : 0;
+        const int sz = q < 3 ? 0 : q - 2;
         if (sz >= nsz) break;
+        const int sl = (q == 0) ? s_u : (q == 1) ? s_r : (q == 2) ? s_rr : (q == 3) ? s_z : s_zz;
+        if (((mask >> sl) & 1) || (q == 0 && (((mask >> s_l) | (mask >> s_ll)) & 1))) qs[nq++] = q;
+    }
+    // Staging of a set: thread -> (level zz, wavenumber kq + 32 b): the 4 radial rows of a wavenumber come as 16-byte (Re, Im)
+    // pairs, KB wavenumbers per thread and batch (the rolled form waited for each wavenumber's 8 scalar loads on its own).
+    // The FIRST batch of the next set (wavenumbers 0 .. 127: 64 registers) is requested before the matrix-core loops of
+    // the current set and consumed after them: the rows come over the fabric (Az does not fit the L2s; every set of every
+    // workgroup pulls up to 256 KB), which a quarter of a large ring's workgroup time used to wait for.
+    constexpr int KB = 4;
+    const int zz = tid >> 5, kq = tid & 31;                      // 512 threads = 16 levels x 32 wavenumbers
+    const bool zin = zz < zc;
+    auto issue = [&](int q, int k0, double2 (&raw)[KB][4]) {
+        const int sz = q < 3 ? 0 : q - 2;
+        const double *a = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + (zin ? zz : 0))) * K2;
+#pragma unroll
+        for (int b = 0; b < KB; b++) {
+            const int kc = min(k0 + kq + 32 * b, km);            // valid address for the padding rows (value dropped)
+#pragma unroll
+            for (int r = 0; r < 4; r++) raw[b][r] = *reinterpret_cast<const double2 *>(a + r * azrow + 2 * kc);
+        }
+    };
+    auto consume = [&](int q, int k0, const double2 (&raw)[KB][4]) {
+        const int d = q < 3 ? q : 0;
+        const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
+        const double f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
+#pragma unroll
+        for (int b = 0; b < KB; b++) {
+            const int k = k0 + kq + 32 * b;
+            if (k >= K4 || zz >= DZC) continue;
+            double cr = 0.0, ci = 0.0;
+            if (zin && k <= km) {
+                cr = f0 * raw[b][0].x + f1 * raw[b][1].x + f2 * raw[b][2].x + f3 * raw[b][3].x;
+                if (k > 0) {
+                    ci = f0 * raw[b][0].y + f1 * raw[b][1].y + f2 * raw[b][2].y + f3 * raw[b][3].y;
+                    const double2 w = phr[k];               // e^{+i k off}
+                    const double tr = cr * w.x - ci * w.y;
+                    ci = 2.0 * (cr * w.y + ci * w.x);
+                    cr = 2.0 * tr;
+                }
+            }
+            Cc[k * CST + zz] = cr;
+            Cs[k * CST + zz] = ci;
+        }
+    };
+    double2 raw0[KB][4];
+    if (nq > 0) issue(qs[0], 0, raw0);
+
+    for (int qi = 0; qi < nq; qi++) {
+        const int q = qs[qi];
         const int slot0 = (q == 0) ? s_u : (q == 1) ? s_r : (q == 2) ? s_rr : (q == 3) ? s_z : s_zz;
         const bool need0 = (mask >> slot0) & 1;
         const bool needl = (q == 0) && ((mask >> s_l) & 1), needll = (q == 0) && ((mask >> s_ll) & 1);
-        if (!need0 && !needl && !needll) continue;
-        const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
-        const double f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
         [[maybe_unused]] const long long dbg_t1 = DFT_NOW();
         __syncthreads();                                        // the previous set has been consumed (and twl is complete)
-        {
-            // thread -> (level zz, wavenumber kq + 32 b): the 4 radial rows of a wavenumber come as 16-byte (Re, Im) pairs, and
-            // the loads of KB wavenumbers are issued together (the rolled form waited for each wavenumber's 8 scalar loads
-            // on its own - 8 round trips per coefficient set, as long as the matrix-core phase itself)
-            constexpr int KB = 4;
-            const int zz = tid >> 5, kq = tid & 31;              // 512 threads = 16 levels x 32 wavenumbers
-            const bool zin = zz < zc;
-            const double *a = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + (zin ? zz : 0))) * K2;
-            for (int k0 = 0; k0 < K4; k0 += 32 * KB) {
-                double2 raw[KB][4];
-#pragma unroll
-                for (int b = 0; b < KB; b++) {
-                    const int k = k0 + kq + 32 * b;
-                    const int kc = min(k, km);                    // valid address for the padding rows (value dropped)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) raw[b][r] = *reinterpret_cast<const double2 *>(a + r * azrow + 2 * kc);
-                }
-#pragma unroll
-                for (int b = 0; b < KB; b++) {
-                    const int k = k0 + kq + 32 * b;
-                    if (k >= K4 || zz >= DZC) continue;
-                    double cr = 0.0, ci = 0.0;
-                    if (zin && k <= km) {
-                        cr = f0 * raw[b][0].x + f1 * raw[b][1].x + f2 * raw[b][2].x + f3 * raw[b][3].x;
-                        if (k > 0) {
-                            ci = f0 * raw[b][0].y + f1 * raw[b][1].y + f2 * raw[b][2].y + f3 * raw[b][3].y;
-                            const double2 w = phr[k];               // e^{+i k off}
-                            const double tr = cr * w.x - ci * w.y;
-                            ci = 2.0 * (cr * w.y + ci * w.x);
-                            cr = 2.0 * tr;
-                        }
-                    }
-                    Cc[k * CST + zz] = cr;
-                    Cs[k * CST + zz] = ci;
-                }
-            }
+        consume(q, 0, raw0);
+        for (int k0 = 32 * KB; k0 < K4; k0 += 32 * KB) {
+            double2 raw[KB][4];
+            issue(q, k0, raw);
+            consume(q, k0, raw);
         }
         __syncthreads();
+        if (qi + 1 < nq) {
+            issue(qs[qi + 1], 0, raw0);
+            asm volatile("" ::: "memory");                      // requested HERE, ahead of the loops
+        }
         dbg_stage += DFT_NOW() - dbg_t1;
 
         const int i = lane & 15, kk = lane >> 4;
