@@ -179,7 +179,16 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
     extern __shared__ double2 smf[];
     FFT_STAMP(0);
     int nslot = 0;
-    const int ring = blockIdx.z, v = blockIdx.y, z0 = blockIdx.x * FZC;
+    // grid = (level chunk, ring or node, variable RANK): workgroups are dispatched in blockIdx order, so every unit of the
+    // variable with the most requested slots goes first and the variables with few (or no) slots fill the tail of the launch
+    const int ring = blockIdx.y, z0 = blockIdx.x * FZC;
+    int v = 0;
+    for (int u = 0; u < V; u++) {
+        const int cu = __popc(slotmask[u]);
+        int before = 0;
+        for (int w = 0; w < V; w++) { const int cw = __popc(slotmask[w]); before += (cw > cu || (cw == cu && w < u)) ? 1 : 0; }
+        if (before == (int)blockIdx.z) v = u;
+    }
     const int zc = min(FZC, nz - z0);
     const int km = kmaxr[ring];
     const int f = threadIdx.x / T, t = threadIdx.x - f * T;       // transform (z pair) and lane within it
@@ -456,7 +465,7 @@ struct InvTarget {          // where an inverse ring launch writes and which uni
 template <int LOGL>
 static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, const double *az, int64_t azrow) {
     const int L = 1 << LOGL;
-    dim3 g((h->nz + fft_fzc(L) - 1) / fft_fzc(L), h->V, tg.n_units);
+    dim3 g((h->nz + fft_fzc(L) - 1) / fft_fzc(L), tg.n_units, h->V);
 #define INV_LAUNCH(NODE, ST)                                                                                                         \
     do {                                                                                                                             \
         if (fft_lds(L, 2) > 65536)                                                                                                   \
