@@ -456,11 +456,11 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
 // BW = wavenumber blocks per workgroup: 64 (zDim 32 / 64), or 32 for zDim 128, where the operator fragments (6 row tiles x
 // 32 K steps = 96 KB) and the node tile (128 levels x 32 blocks) have to share the 160 KB; then wave w owns column tile
 // w & 1 and the row tiles (w >> 1), (w >> 1) + 4.
-template <int NZ, int BW = 64>
-__global__ void __launch_bounds__(512, 2)
+template <int NZ, int BW = 64, int THREADS = 512>
+__global__ void __launch_bounds__(THREADS, 2)
 k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *__restrict__ phi, const double *__restrict__ wq,
            const double *__restrict__ CB, int ncells, int V, int Zb, int K2, int64_t C, int cps) {
-    constexpr int NG = 512 / BW;                      // level groups: thread = (group g, block lb), levels z = g + NG i
+    constexpr int NG = THREADS / BW;                  // level groups: thread = (group g, block lb), levels z = g + NG i
     constexpr int ZPT = NZ / NG, KS = NZ / 4, LS = BW + 16;      // LS: the 4 levels a K step reads fall in disjoint bank halves
     constexpr int MTMAX = BW == 64 ? 4 : 6;           // row tiles of 16 modes: b_zDim <= 64 / <= 96
     __shared__ double As[NZ * LS];
@@ -480,7 +480,7 @@ k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *
     // this wave's column tile nt and row tiles mt0, mt1 (nmt of them)
     const int nt = BW == 64 ? (wv & 3) : (wv & 1);
     const int mt0 = BW == 64 ? (wv < 4 ? 0 : mhalf) : (wv >> 1);
-    const int mt1 = BW == 64 ? mt0 + 1 : mt0 + 4;
+    const int mt1 = BW == 64 ? mt0 + 1 : mt0 + THREADS / 128;      // BW = 32: two column tiles, the waves of a column tile share the row tiles
     const int nmt = BW == 64 ? (wv < 4 ? mhalf : MT - mhalf) : (mt0 >= MT ? 0 : mt1 < MT ? 2 : 1);
     const int n = lane & 15, kk = lane >> 4;
     // (kept in LDS in fragment order [row tile][K step][lane]: a conflict-free 8-byte read per MFMA; in registers the two
@@ -1973,11 +1973,15 @@ void launch_sb(sx_handle *h) {
             // registers for a second set; or SX_SBW_PF=0) about 1.5 workgroups per CU as before.  On large tiles never fewer
             // than 6 cells so that the warm-up stays below half of the reads
             const bool mf = h->sbw_mfma && (h->nz <= 64 ? h->Zb <= 64 : h->Zb <= 96);      // matrix-core contraction + prefetch (k_sbw_mfma)
-            const int bw = (mf && h->nz == 128) ? 32 : 64;                   // wavenumber blocks per workgroup
+            // zDim 64: 256-thread workgroups of 32 blocks, two per CU - one loads while the other contracts (0.127 -> 0.118 ms;
+            // SX_SBW_T256=0 restores the 512-thread form)
+            static const bool t256_env = !(getenv("SX_SBW_T256") && atoi(getenv("SX_SBW_T256")) == 0);
+            const bool t256 = t256_env && mf && h->nz == 64;
+            const int bw = ((mf && h->nz == 128) || t256) ? 32 : 64;         // wavenumber blocks per workgroup
             const int groups = ((h->K2 + bw - 1) / bw) * h->V;
             const bool pf = (h->sbw_prefetch && h->nz <= 64) || mf;
             static const int seg_env = getenv("SX_SBW_SEG") ? atoi(getenv("SX_SBW_SEG")) : 0;      // experiments: segments per (block group, variable)
-            const int nseg = seg_env > 0 ? seg_env : std::max(1, (mf && h->nz == 128 ? 512 : pf || h->nz == 128 ? 256 : 384) / groups);
+            const int nseg = seg_env > 0 ? seg_env : std::max(1, ((mf && h->nz == 128) || t256 ? 512 : pf || h->nz == 128 ? 256 : 384) / groups);
             // small tiles (multi-GPU strong scaling): the kernel is then one workgroup's latency chain, which is proportional
             // to the cells it walks, so short segments (down to 2 cells + 3 warm-up) beat the saved re-reads
             const int cps = std::max(h->ncells <= 64 ? 2 : 6, (h->ncells + nseg - 1) / nseg);
@@ -1992,7 +1996,8 @@ void launch_sb(sx_handle *h) {
 #endif
             auto kern = h->nz == 64 ? (pf ? k_sbw<64, true> : k_sbw<64, false>) : h->nz == 32 ? (pf ? k_sbw<32, true> : k_sbw<32, false>) : k_sbw<128, false>;
             if (mf) kern = h->nz == 64 ? k_sbw_mfma<64> : h->nz == 32 ? k_sbw_mfma<32> : k_sbw_mfma<128, 32>;
-            hipLaunchKernelGGL(kern, gw, dim3(512), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->d_CB, h->ncells,
+            if (t256) kern = k_sbw_mfma<64, 32, 256>;
+            hipLaunchKernelGGL(kern, gw, dim3(t256 ? 256 : 512), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->d_CB, h->ncells,
                                h->V, h->Zb, h->K2, h->C, cps);
             HIPCHK(hipGetLastError());
             timer_end(h);
