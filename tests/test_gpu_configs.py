@@ -132,6 +132,21 @@ def test_config4_full_size_two_steps_against_the_c_oracle():
     _check(hip, orc, [0, 1, 125, 126, 127, 300, 512], "config 4 shape (RLZ 513 x 256 x 64, uniform rings), 2 steps")
 
 
+def test_config4_native_equivalent_full_size_against_the_c_oracle():
+    """The native-equivalent shape of config 4 (bench.py's `native_equivalent`): 85 cells = 255 ragged rings of
+    4 + 4 ri points keeping ri wavenumbers, 64 levels, 8.4 M points - the matrix-core DFT kernels at the lengths they are
+    timed on (8 .. 1024 points, kmax up to 255) against the C oracle, 2 steps."""
+    case = cases.rlz_hrbl(num_cells=85, zDim=64)
+    case["ts"] = 0.2
+    hip = cases.HipModel(case)
+    assert hip.run.tiles[0].N == 8421120                 # 131,580 horizontal points (rings of 8 .. 1024) x 64 levels
+    orc = cases.OracleModel(case)
+    for _ in range(2):
+        hip.step()
+        orc.step()
+    _check(hip, orc, [0, 1, 127, 128, 253, 254], "config 4, native-equivalent shape (255 ragged rings x 64 levels, kmax 255), 2 steps")
+
+
 def test_config4_full_size_forward_transform_is_linear():
     import scythe_jl_amd as S
     run = _bench_model(1)
