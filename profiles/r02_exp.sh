@@ -1,9 +1,5 @@
 #!/bin/bash
-ROOT=$(pwd); OUT=$ROOT/gpurun_out/r02; mkdir -p $OUT
-cd /tmp; export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5prof -o c5 -- python3 $ROOT/bench.py --workload rlz_1023x512x128 --storage f32 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/config5_under_rocprof.json 2> $OUT/c5prof.log
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/natprof -o nat -- python3 $ROOT/profiles/native_timers.py 10 > $OUT/native_under_rocprof.json 2> $OUT/natprof.log
-cd $ROOT
-cp $(find $OUT/c5prof -name "*kernel_stats.csv" | head -1) $OUT/config5_f32_kernel_stats.csv
-cp $(find $OUT/natprof -name "*kernel_stats.csv" | head -1) $OUT/native_kernel_stats.csv
-head -12 $OUT/config5_f32_kernel_stats.csv | cut -c1-70,250-400; head -9 $OUT/native_kernel_stats.csv | cut -c1-70,250-400
+OUT=$(pwd)/gpurun_out/r02; mkdir -p $OUT
+for r in 0 1 8; do SX_ZINV_RPW=$r timeout -k 10 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-native 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('rpw $r', round(d['value'],1), {k: round(x,4) for k,x in d['kernels_ms_per_step'].items() if k in ('k_zinv','k_node_fft','k_rl_inverse')})"; done
+timeout -k 10 600 python bench.py --workload rlz_1023x512x128 --storage f32 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('config5 f32', round(d['value'],1), {k: round(x,4) for k,x in d['kernels_ms_per_step'].items()})"
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -q -x -k "rz or rlz or hrbl or config3 or config5 or tiles" > $OUT/gpu_tests_subset.log 2>&1; echo "pytest rc=$?"; tail -2 $OUT/gpu_tests_subset.log
