@@ -183,6 +183,23 @@ def test_config4_full_size_node_space_path_equals_ring_wise_path(monkeypatch):
     b.close()
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_config4_full_size_two_stream_modes_are_bit_identical(monkeypatch, mode):
+    """SX_OVERLAP=1 / 2 (the inner-ring chain on a second stream) only reorders kernels that touch disjoint
+    points: after 4 steps the fields are bit-identical to the one-stream run."""
+    a = _bench_model(1)
+    monkeypatch.setenv("SX_OVERLAP", mode)
+    b = _bench_model(1)
+    for _ in range(4):
+        a.step()
+        b.step()
+    fa, fb = a.tiles[0].var_np1, b.tiles[0].var_np1
+    assert not a.tiles[0].check_nan() and not b.tiles[0].check_nan()
+    assert np.array_equal(fa, fb)
+    a.close()
+    b.close()
+
+
 def test_config4_full_size_azimuthal_derivative_slots_are_the_spectral_derivatives():
     """tileTransform! at full size: on every sampled ring and level, the d/dlambda and d2/dlambda2 slots equal the
     FFT derivatives (numpy, on the host) of the value slot - the three slots come from one spectrum."""
