@@ -83,24 +83,26 @@ def test_config3_rz_513x128_semiimplicit_three_way():
     assert three["HIP vs LU oracle"][1] <= 2.0 * three["LU oracle vs extended"][1] + 1e-12
 
 
-def _bench_model(num_tiles, exchange="a2a", split="reference", workload="rlz_513x256x64", storage="f64"):
+def _bench_model(num_tiles, exchange="a2a", split="reference", workload="rlz_513x256x64", storage="f64", impl="torch"):
     import bench
     import scythe_jl_amd as S
     kw, L = bench.grid_kwargs(workload)
     gp = S.GridParameters(ring_uniform_L=L, storage=storage, **kw)
     mp = S.ModelParameters(ts=bench.TS_OF.get(workload, bench.TS), equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
                            physical_params=dict(bench.PAR))
-    run = S.ModelRun(mp, num_tiles=num_tiles, device="cuda", exchange=exchange, split=split)
+    run = S.ModelRun(mp, num_tiles=num_tiles, device="cuda", exchange=exchange, split=split, impl=impl)
     run.set_initial_conditions([bench.initial_condition(S.getGridpoints(g)) for g in run.tiles])
     return run
 
 
 def test_config4_full_size_tiling_invariance():
-    """RLZ 513 x 256 x 64, 6 variables: 3 even radial tiles and 4 cost-balanced ones (transposed solve) reproduce the
-    one-tile run."""
+    """RLZ 513 x 256 x 64, 6 variables: 3 even radial tiles and 4 cost-balanced ones (transposed solve, Python-side stand-in
+    for the exchange), and 8 cost-balanced tiles with the exchange done INSIDE the library (the RCCL path's buffers and
+    offset tables through the loopback transport, both protocols) reproduce the one-tile run."""
     fields = []
-    for nt, split in ((1, "reference"), (3, "reference"), (4, "cost")):
-        run = _bench_model(nt, split=split)
+    for nt, split, impl, exch in ((1, "reference", "torch", "a2a"), (3, "reference", "torch", "a2a"), (4, "cost", "torch", "a2a"),
+                                  (8, "cost", "lib", "a2a"), (8, "cost", "lib", "gather")):
+        run = _bench_model(nt, split=split, impl=impl, exchange=exch)
         for _ in range(3):
             run.step()
         vals = []
