@@ -2,7 +2,9 @@
 """bench.py - model steps/sec of the RLZ 512x256x64 shallow-water configuration on N MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1: either launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+  (RANK / WORLD_SIZE in the environment), or invoked plainly - then this process starts that launcher itself as a CHILD
+  process before anything here touches the GPU, relays rank 0's JSON line and exits with the launcher's status.
 
 One "step" is one pass of model_loop's body (src/semiimplicit.jl:268-297): tileTransform! -> equation set
 (Oneway_ShallowWater_HeightResolvedBL) -> explicit_timestep -> spectralTransform! -> halo/sum -> splineTransform!.
@@ -114,6 +116,23 @@ def cpu_baseline(workload, sample_cells, steps):
                          sample_cells, dt_solve)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher in front: start `torch.distributed.run` with N ranks of this very
+    command line as a child process (never exec: this is called before torch or HIP are imported, and the parent never
+    touches the GPU), pass the ranks' stdout / stderr through and return the launcher's exit status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")       # what the launcher would set anyway, without its warning
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +163,8 @@ def main():
 
     # dmabuf IPC for RCCL / cross-process device buffers; must be in the environment before the HIP runtime starts
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     import scythe_jl_amd as S
 
@@ -180,18 +201,16 @@ def main():
         return r
 
     if world > 1 and impl == "lib":
+        # LibExchange itself makes the ranks agree before its first collective (probe on every rank -> all_gather of the
+        # outcome -> unique-id broadcast -> ncclCommInitRank), so it raises on EVERY rank or on none and all ranks take the same
+        # branch here; a failure inside ncclCommInitRank itself is fatal for the job, as for any RCCL program.
         run, err = None, ""
         try:
             run = make_run("lib")
-        except Exception as e:          # RCCL could not be bound / initialised inside the library
-            err = str(e)[:120]
-        # every rank must take the same path: agree on the outcome before anybody moves on
-        okf = torch.tensor([1 if run is not None else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
-        if int(okf.item()) == 0:
-            print("bench.py: in-library exchange unavailable on some rank (%s), using torch.distributed" % err, file=sys.stderr)
-            if run is not None:
-                run.close()
+        except RuntimeError as e:       # RCCL could not be bound / the exchange buffers not set up, on some rank
+            err = str(e)[:160]
+        if run is None:
+            print("bench.py: in-library exchange unavailable (%s), using torch.distributed" % err, file=sys.stderr)
             impl = "torch (lib failed: %s)" % err
             run = make_run("torch")
         if impl == "lib" and not args.no_selfcheck:
@@ -328,14 +347,15 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_cells, args.cpu_steps)
             except Exception as e:   # the baseline is a reported side figure; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        if selfcheck is not None and not (selfcheck < 1e-10):
-            out["value"] = None
-            out["error"] = "in-library RCCL exchange and torch.distributed exchange disagree: %g" % selfcheck
-            nan = True
         if nan:
             # a run that blew up is not a throughput measurement: no value, non-zero exit
             out["value"] = None
             out["error"] = "NaN in the model state after the timed steps (checkCFL)"
+        if selfcheck is not None and not (selfcheck < 1e-10):
+            out["value"] = None
+            out["error"] = "in-library RCCL exchange and torch.distributed exchange disagree: %g" % selfcheck + (
+                "; " + out["error"] if "error" in out else "")
+            nan = True
         print(json.dumps(out), flush=True)
     run.close()
     if dist is not None:

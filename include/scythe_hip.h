@@ -247,8 +247,14 @@ int sx_a2a_unpack_a(sx_handle *h, const void *dev_recv);
  * patch solve).  tile_cell0 / tile_num_cells describe all n tiles (calcTileSizes rows 4 and 3, 0-based cell0).
  * sx_comm_attach does the same with a communicator the host already owns (ncclComm_t, e.g. from NCCL.jl); it is not
  * destroyed with the handle.  After sx_exchange the patch A coefficients this tile evaluates are in place for the next
- * sx_advance / sx_tile_transform. */
+ * sx_advance / sx_tile_transform.
+ * sx_comm_prepare is the part of sx_comm_init / sx_comm_attach that can fail on one rank alone (binding librccl, checking
+ * the tile table, allocating the exchange buffers) and is NOT collective: a host that wants to fall back cleanly calls it on
+ * every rank, agrees on the outcome through its own channel, and enters the collective sx_comm_init on all ranks or on none
+ * (sx_comm_init prepares by itself when this was not called).  A failed set-up leaves the handle without exchange state. */
 int sx_comm_unique_id(char *out128);
+int sx_comm_prepare(sx_handle *h, int32_t n_tiles, int32_t my_tile, const int32_t *tile_cell0, const int32_t *tile_num_cells,
+                    int32_t mode);
 int sx_comm_init(sx_handle *h, int32_t n_tiles, int32_t my_tile, const int32_t *tile_cell0, const int32_t *tile_num_cells,
                  int32_t mode, const char *id128);
 int sx_comm_attach(sx_handle *h, int32_t n_tiles, int32_t my_tile, const int32_t *tile_cell0, const int32_t *tile_num_cells,

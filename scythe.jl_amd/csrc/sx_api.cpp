@@ -984,16 +984,30 @@ int sx_patch_a_device(sx_handle *h, void **p, int64_t *rows, int64_t *cols) {
 }
 
 // ---- transposed (all-to-all) patch solve ---------------------------------------------------------------------------
+}  // extern "C"
+
+namespace sx {
+// The tile table every exchange protocol is configured from (calcTileSizes rows 4 and 3): entry `me` is this handle's tile,
+// the tiles are contiguous, cover the patch and have at least 3 cells each (calcTileSizes' own rule, src/semiimplicit.jl:141-153;
+// with fewer the 3 halo rows a tile sends would overlap the 3 rows that receive its predecessor's halo).
+bool tile_table_ok(const sx_handle *h, int n, int me, const int32_t *cell0, const int32_t *ncells) {
+    if (!h || !cell0 || !ncells || n < 1 || me < 0 || me >= n) { set_error("invalid tile table argument"); return false; }
+    if (cell0[me] != h->cell0 || ncells[me] != h->ncells) { set_error("tile table does not match this handle"); return false; }
+    int c = 0;
+    for (int t = 0; t < n; t++) {
+        if (cell0[t] != c || (ncells[t] < 3 && n > 1)) { set_error("tiles must be contiguous with at least 3 cells each"); return false; }
+        c += ncells[t];
+    }
+    if (c != h->nc) { set_error("tiles do not cover the patch"); return false; }
+    return true;
+}
+}  // namespace sx
+
+extern "C" {
 int sx_a2a_configure(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells) {
     clear_error();
     if (!h || !cell0 || !ncells || n < 1 || me < 0 || me >= n) { set_error("invalid argument"); return 1; }
-    if (cell0[me] != h->cell0 || ncells[me] != h->ncells) { set_error("tile table does not match this handle"); return 1; }
-    int c = 0;
-    for (int t = 0; t < n; t++) {
-        if (cell0[t] != c || ncells[t] < 3) { set_error("tiles must be contiguous with at least 3 cells each"); return 1; }
-        c += ncells[t];
-    }
-    if (c != h->nc) { set_error("tiles do not cover the patch"); return 1; }
+    if (!tile_table_ok(h, n, me, cell0, ncells)) return 1;
     h->a2a_n = n; h->a2a_me = me;
     h->a2a_cell0.assign(cell0, cell0 + n);
     h->a2a_ncells.assign(ncells, ncells + n);

@@ -8,6 +8,7 @@
 #include "sx_internal.hpp"
 #include <dlfcn.h>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 
 namespace sx {
@@ -57,6 +58,17 @@ static Rccl *rccl() {
         if (rc_ != 0) { set_error(std::string(#call) + ": " + R->GetErrorString(rc_)); return 1; }   \
     } while (0)
 
+// ncclGroupStart / ncclGroupEnd as a scope: an early return between the two (a failed ncclSend / ncclRecv) must still close
+// the thread's group, or every later RCCL call of this thread - torch's included - is queued and never launched
+struct GroupScope {
+    Rccl *R;
+    bool open = false;
+    explicit GroupScope(Rccl *r) : R(r) {}
+    int start() { const int rc = R->GroupStart(); open = (rc == 0); return rc; }
+    int end() { open = false; return R->GroupEnd(); }
+    ~GroupScope() { if (open) R->GroupEnd(); }
+};
+
 struct CommState {
     NcclComm comm = nullptr;
     bool owned = false;            // created by sx_comm_init (destroyed with the handle) vs attached by the host
@@ -68,6 +80,7 @@ struct CommState {
     // gather: [tile][max_rows][C] + the 3 received halo rows
     double *gbuf = nullptr, *halo = nullptr;
     int64_t max_rows = 0;
+    std::vector<void *> bufs;      // every device buffer of this state (also listed in sx_handle::allocs until released)
 };
 
 static bool dev_alloc(sx_handle *h, double **p, int64_t n) {
@@ -76,6 +89,7 @@ static bool dev_alloc(sx_handle *h, double **p, int64_t n) {
     if (hipMalloc(&d, bytes) != hipSuccess || hipMemset(d, 0, bytes) != hipSuccess) { set_error("hipMalloc failed (exchange buffers)"); return false; }
     h->allocs.push_back(d);
     h->dev_bytes += bytes;
+    if (h->comm_state) ((CommState *)h->comm_state)->bufs.push_back(d);
     *p = (double *)d;
     return true;
 }
@@ -84,6 +98,18 @@ void comm_release(sx_handle *h) {
     CommState *c = (CommState *)h->comm_state;
     if (!c) return;
     if (c->owned && c->comm) { Rccl *R = rccl(); if (R) R->CommDestroy(c->comm); }
+    // the exchange buffers go with the state (a repeated sx_comm_init must not pile them up until sx_destroy); the kernels
+    // may still be reading them, and the bindings into them must not outlive them
+    if (!c->bufs.empty()) {
+        hipStreamSynchronize(h->stream);
+        sx_bind_tile_b(h, nullptr);
+        sx_bind_patch_b(h, nullptr, nullptr);
+        for (void *b : c->bufs) {
+            auto it = std::find(h->allocs.begin(), h->allocs.end(), b);
+            if (it != h->allocs.end()) h->allocs.erase(it);
+            hipFree(b);
+        }
+    }
     delete c;
     h->comm_state = nullptr;
 }
@@ -106,6 +132,9 @@ int sx_comm_unique_id(char *out128) {
 
 static int configure(sx_handle *h, CommState *c, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode) {
     if (mode != 0 && mode != 1) { set_error("exchange mode must be 0 (all-to-all) or 1 (gather)"); return 1; }
+    // both protocols index patch rows through this table (mode 1 writes a b_rDim-sized offset vector from it, and a tile of
+    // fewer than 3 cells would make the halo rows it sends overlap the rows that receive the halo add)
+    if (!tile_table_ok(h, n, me, cell0, ncells)) return 1;
     c->n = n; c->me = me; c->mode = mode;
     c->cell0.assign(cell0, cell0 + n);
     c->ncells.assign(ncells, ncells + n);
@@ -121,7 +150,6 @@ static int configure(sx_handle *h, CommState *c, int32_t n, int32_t me, const in
         }
         if (!dev_alloc(h, &c->tile_buf, to) || !dev_alloc(h, &c->tile_buf2, to) || !dev_alloc(h, &c->own_in, oo) || !dev_alloc(h, &c->own_out, oo)) return 1;
     } else {
-        if (cell0[me] != h->cell0 || ncells[me] != h->ncells) { set_error("tile table does not match this handle"); return 1; }
         c->max_rows = 0;
         for (int t = 0; t < n; t++) c->max_rows = std::max<int64_t>(c->max_rows, ncells[t] + 3);
         if (!dev_alloc(h, &c->gbuf, (int64_t)n * c->max_rows * h->C) || !dev_alloc(h, &c->halo, 3 * h->C)) return 1;
@@ -136,18 +164,53 @@ static int configure(sx_handle *h, CommState *c, int32_t n, int32_t me, const in
     return 0;
 }
 
-int sx_comm_init(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode, const char *id128) {
-    clear_error();
-    if (!h || !cell0 || !ncells || !id128 || n < 1 || me < 0 || me >= n) { set_error("sx_comm_init: invalid argument"); return 1; }
-    Rccl *R = rccl();
-    if (!R) return 1;
+// Everything of the set-up that can fail on ONE rank alone - binding librccl, validating the tile table, the exchange buffers -
+// happens here, before the collective ncclCommInitRank: a host can run this on every rank, agree on the outcome (any
+// side channel will do) and only then enter sx_comm_init, which all ranks or none must enter.
+static int prepare(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode) {
+    if (!rccl()) return 1;
     comm_release(h);
     CommState *c = new CommState();
     h->comm_state = c;
-    if (configure(h, c, n, me, cell0, ncells, mode)) return 1;
+    if (configure(h, c, n, me, cell0, ncells, mode)) {
+        const std::string keep = sx_last_error();     // comm_release re-binds the B arrays, which clears the message
+        comm_release(h);
+        set_error(keep);
+        return 1;
+    }
+    return 0;
+}
+
+static bool prepared_as(const sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode) {
+    const CommState *c = (const CommState *)h->comm_state;
+    if (!c || c->comm || c->n != n || c->me != me || c->mode != mode) return false;
+    for (int t = 0; t < n; t++)
+        if (c->cell0[t] != cell0[t] || c->ncells[t] != ncells[t]) return false;
+    return true;
+}
+
+int sx_comm_prepare(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode) {
+    clear_error();
+    if (!h || !cell0 || !ncells || n < 1 || me < 0 || me >= n) { set_error("sx_comm_prepare: invalid argument"); return 1; }
+    return prepare(h, n, me, cell0, ncells, mode);
+}
+
+int sx_comm_init(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode, const char *id128) {
+    clear_error();
+    if (!h || !cell0 || !ncells || !id128 || n < 1 || me < 0 || me >= n) { set_error("sx_comm_init: invalid argument"); return 1; }
+    if (!prepared_as(h, n, me, cell0, ncells, mode) && prepare(h, n, me, cell0, ncells, mode)) return 1;
+    Rccl *R = rccl();
+    CommState *c = (CommState *)h->comm_state;
     NcclUniqueId id;
     std::memcpy(id.internal, id128, 128);
-    NCCLOK(R->CommInitRank(&c->comm, n, id, me));      // collective over the n tiles; uses the calling thread's current device
+    const int rc = R->CommInitRank(&c->comm, n, id, me);      // collective over the n tiles; uses the calling thread's current device
+    if (rc != 0) {
+        const std::string msg = std::string("ncclCommInitRank: ") + R->GetErrorString(rc);
+        c->comm = nullptr;
+        comm_release(h);                                      // never leave a half-configured state behind
+        set_error(msg);
+        return 1;
+    }
     c->owned = true;
     return 0;
 }
@@ -155,11 +218,8 @@ int sx_comm_init(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, cons
 int sx_comm_attach(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode, void *nccl_comm) {
     clear_error();
     if (!h || !cell0 || !ncells || !nccl_comm || n < 1 || me < 0 || me >= n) { set_error("sx_comm_attach: invalid argument"); return 1; }
-    if (!rccl()) return 1;
-    comm_release(h);
-    CommState *c = new CommState();
-    h->comm_state = c;
-    if (configure(h, c, n, me, cell0, ncells, mode)) return 1;
+    if (!prepared_as(h, n, me, cell0, ncells, mode) && prepare(h, n, me, cell0, ncells, mode)) return 1;
+    CommState *c = (CommState *)h->comm_state;
     c->comm = nccl_comm;
     c->owned = false;
     return 0;
@@ -176,7 +236,12 @@ int sx_comm_init_local(sx_handle **hs, int32_t n, const int32_t *cell0, const in
         comm_release(hs[t]);
         CommState *c = new CommState();
         hs[t]->comm_state = c;
-        if (configure(hs[t], c, n, t, cell0, ncells, mode)) return 1;
+        if (configure(hs[t], c, n, t, cell0, ncells, mode)) {
+            const std::string keep = sx_last_error();
+            for (int u = 0; u <= t; u++) comm_release(hs[u]);
+            set_error(keep);
+            return 1;
+        }
     }
     return 0;
 }
@@ -193,10 +258,24 @@ int sx_exchange_local(sx_handle **hs, int32_t n) {
     auto copy = [&](double *dst, const double *src, int64_t cnt, hipStream_t s) {
         return cnt == 0 || hipMemcpyAsync(dst, src, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToDevice, s) == hipSuccess;
     };
-    // all tiles share one device; run everything on tile 0's stream so that the copies are ordered with the kernels
+    // all tiles share one device; run everything on tile 0's stream so that the copies are ordered with the kernels.  A tile
+    // bound to another stream may still have work queued there: tile 0's stream first waits for it, and that stream waits
+    // for the exchange afterwards.
     hipStream_t s0 = hs[0]->stream;
     std::vector<hipStream_t> keep(n);
-    for (int t = 0; t < n; t++) { keep[t] = hs[t]->stream; hs[t]->stream = s0; }
+    bool foreign = false;
+    for (int t = 0; t < n; t++) { keep[t] = hs[t]->stream; foreign |= keep[t] != s0; }
+    hipEvent_t ev = nullptr;
+    if (foreign) {
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return 1; }
+        for (int t = 1; t < n; t++)
+            if (keep[t] != s0 && (hipEventRecord(ev, keep[t]) != hipSuccess || hipStreamWaitEvent(s0, ev, 0) != hipSuccess)) {
+                hipEventDestroy(ev);
+                set_error("stream ordering of sx_exchange_local failed");
+                return 1;
+            }
+    }
+    for (int t = 0; t < n; t++) hs[t]->stream = s0;
     int rc = 0;
     if (cs[0]->mode == 0) {
         for (int t = 0; t < n && !rc; t++) rc = sx_a2a_pack_b(hs[t], cs[t]->tile_buf);
@@ -226,6 +305,13 @@ int sx_exchange_local(sx_handle **hs, int32_t n) {
         for (int t = 0; t < n && !rc; t++) rc = sx_spline_transform(hs[t]);
     }
     for (int t = 0; t < n; t++) hs[t]->stream = keep[t];
+    if (foreign) {
+        bool ok = hipEventRecord(ev, s0) == hipSuccess;
+        for (int t = 1; t < n && ok; t++)
+            if (keep[t] != s0) ok = hipStreamWaitEvent(keep[t], ev, 0) == hipSuccess;
+        hipEventDestroy(ev);
+        if (!ok && !rc) { set_error("stream ordering of sx_exchange_local failed"); rc = 1; }
+    }
     return rc;
 }
 
@@ -235,33 +321,35 @@ int sx_exchange(sx_handle *h) {
     CommState *c = (CommState *)h->comm_state;
     Rccl *R = rccl();
     if (!R) return 1;
+    if (!c->comm) { set_error("sx_exchange: no communicator (sx_comm_prepare without sx_comm_init / sx_comm_attach, or tiles set up for sx_exchange_local)"); return 1; }
     const int n = c->n, me = c->me;
     hipStream_t s = h->stream;
+    GroupScope grp(R);
     if (c->mode == 0) {
         // transposed solve: B rows -> owners of the column ranges, solve my columns for the whole patch, A rows back
         if (sx_a2a_pack_b(h, c->tile_buf)) return 1;
-        NCCLOK(R->GroupStart());
+        NCCLOK(grp.start());
         for (int d = 0; d < n; d++) {
             NCCLOK(R->Send(c->tile_buf + c->tile_off[d], (size_t)c->tile_cnt[d], NCCL_DOUBLE, d, c->comm, s));
             NCCLOK(R->Recv(c->own_in + c->own_off[d], (size_t)c->own_cnt[d], NCCL_DOUBLE, d, c->comm, s));
         }
-        NCCLOK(R->GroupEnd());
+        NCCLOK(grp.end());
         if (sx_a2a_solve(h, c->own_in, c->own_out)) return 1;
-        NCCLOK(R->GroupStart());
+        NCCLOK(grp.start());
         for (int t = 0; t < n; t++) {
             NCCLOK(R->Send(c->own_out + c->own_off[t], (size_t)c->own_cnt[t], NCCL_DOUBLE, t, c->comm, s));
             NCCLOK(R->Recv(c->tile_buf2 + c->tile_off[t], (size_t)c->tile_cnt[t], NCCL_DOUBLE, t, c->comm, s));
         }
-        NCCLOK(R->GroupEnd());
+        NCCLOK(grp.end());
         return sx_a2a_unpack_a(h, c->tile_buf2);
     }
     // the reference's protocol: halo rows tile -> tile + 1 (:320-329), owned rows to everybody (:272-282), redundant solve (:285)
     double *mine = c->gbuf + (int64_t)me * c->max_rows * h->C;
     if (n > 1) {
-        NCCLOK(R->GroupStart());
+        NCCLOK(grp.start());
         if (me < n - 1) NCCLOK(R->Send(mine + (int64_t)c->ncells[me] * h->C, (size_t)(3 * h->C), NCCL_DOUBLE, me + 1, c->comm, s));
         if (me > 0) NCCLOK(R->Recv(c->halo, (size_t)(3 * h->C), NCCL_DOUBLE, me - 1, c->comm, s));
-        NCCLOK(R->GroupEnd());
+        NCCLOK(grp.end());
         if (me > 0 && sx_halo_add(h, c->halo)) return 1;
     }
     NCCLOK(R->AllGather(mine, c->gbuf, (size_t)(c->max_rows * h->C), NCCL_DOUBLE, c->comm, s));     // in place: my block is my slot

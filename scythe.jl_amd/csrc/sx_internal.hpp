@@ -193,6 +193,7 @@ void timers_flush(sx_handle *h);
 void set_error(const std::string &msg);
 void clear_error();
 void comm_release(sx_handle *h);
+bool tile_table_ok(const sx_handle *h, int n, int me, const int32_t *cell0, const int32_t *ncells);
 #ifdef SX_PHASES
 void phases_dump();
 void fft_phases_dump();

@@ -249,7 +249,21 @@ class LibExchange:
         if unique_id is None:
             import torch.distributed as dist
             rank, world = dist.get_rank(group), dist.get_world_size(group)
-            box = [comm_unique_id() if rank == 0 else None]
+            assert world == layout.num_tiles
+            # Everything that can fail on one rank alone happens BEFORE the first collective, and the ranks agree on the outcome:
+            # a rank that raised here while the others sat in the broadcast (or in ncclCommInitRank) would hang the job.
+            err, uid = "", None
+            try:
+                tile.comm_prepare(layout.cell0, layout.ncells, rank, mode)      # librccl, tile table, buffers: not collective
+                uid = comm_unique_id()                                          # ncclGetUniqueId: not collective either
+            except Exception as e:
+                err = str(e)
+            oks = [None] * world
+            dist.all_gather_object(oks, err, group=group)
+            if any(oks):
+                raise RuntimeError("in-library exchange unavailable on rank(s) %s: %s"
+                                   % ([r for r, e in enumerate(oks) if e], next(e for e in oks if e)))
+            box = [uid if rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
             unique_id = box[0]
         else:
@@ -274,7 +288,8 @@ class LocalLibExchange:
         self.hs = (C.c_void_p * self.n)(*[g._h for g in tiles])
         c0 = (C.c_int32 * self.n)(*layout.cell0)
         nc = (C.c_int32 * self.n)(*layout.ncells)
-        L.check(L.load().sx_comm_init_local(self.hs, self.n, c0, nc, {"a2a": 0, "gather": 1}[mode]))
+        from .model import EXCHANGE_MODES
+        L.check(L.load().sx_comm_init_local(self.hs, self.n, c0, nc, EXCHANGE_MODES[mode]))
 
     def exchange_and_solve(self):
         self._L.check(self._L.load().sx_exchange_local(self.hs, self.n))
@@ -339,7 +354,9 @@ class ModelRun:
             pass
 
     def _check_stream(self):
-        if self._stream is not None and self.impl == "torch":
+        # every implementation but the in-library one issues torch operations (collectives, or the copies of the Local*
+        # exchanges) on torch's CURRENT stream: the tiles' kernels must follow it
+        if self._stream is not None and self.impl != "lib":
             cur = _torch().cuda.current_stream().cuda_stream
             if cur != self._stream:          # the caller entered a torch.cuda.stream(...) context: follow it
                 self._stream = cur
@@ -383,6 +400,31 @@ class ModelRun:
             g.tileTransform_()
             out.append(g.physical)
         return np.concatenate(out, axis=0)
+
+    def patch_spectral(self):
+        """mtile.patchSpectral as the master pulls it from a worker for output (src/semiimplicit.jl:288-293): the patch's A
+        coefficients [s_patch, V].  With the reference's protocol every tile holds the whole patch; with the transposed solve a
+        tile only holds the rows it evaluates, so the patch array is assembled from every tile's OWNED rows (output cadence
+        only; one process per GPU: gathered to rank 0, other ranks return None)."""
+        if self.exchange_kind != "a2a":
+            return self.tiles[0].patchSpectral
+        nb = self.layout.b_rDim
+        parts = []
+        for t, g in zip(self.tile_ids, self.tiles):
+            a = g.patchSpectral.reshape(-1, nb, g.V, order="F")             # [z-mode x block, node, var], node fastest
+            c0 = self.layout.cell0[t]
+            parts.append((c0, np.ascontiguousarray(a[:, c0:c0 + self.layout.owned_rows(t), :])))
+        if self.use_dist:
+            import torch.distributed as dist
+            box = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+            dist.gather_object(parts, box, dst=0)
+            if dist.get_rank() != 0:
+                return None
+            parts = [p for ps in box for p in ps]
+        out = np.zeros((parts[0][1].shape[0], nb, parts[0][1].shape[2]))
+        for c0, rows in parts:
+            out[:, c0:c0 + rows.shape[1], :] = rows
+        return out.reshape(-1, out.shape[2], order="F")
 
     def synchronize(self):
         for g in self.tiles:

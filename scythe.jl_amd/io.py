@@ -93,8 +93,8 @@ def write_output(run, model, time, derivatives=True, spectral=True):
     arr = np.concatenate(rows, axis=0)
     header = _COORD[gp.geometry] + [n + _SUFFIX[s] for s in slots for n in names]
     np.savetxt(path, arr, delimiter=",", header=",".join(header), comments="", fmt="%.17g")
-    if spectral and run.exchange_kind != "a2a":      # in the transposed solve no tile holds the whole patch's coefficients
-        a = run.tiles[0].patchSpectral
+    a = run.patch_spectral() if spectral else None   # transposed solve: assembled from the tiles' owned rows (rank 0 writes)
+    if a is not None:
         idx = np.arange(1, a.shape[0] + 1, dtype=np.float64)[:, None]
         np.savetxt(os.path.join(model.output_dir, "spectral_out_%s.csv" % tag), np.concatenate([idx, a], axis=1), delimiter=",",
                    header=",".join(["i"] + names), comments="", fmt="%.17g")

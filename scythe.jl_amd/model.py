@@ -397,13 +397,19 @@ class Grid:
         return tuple(a)
 
     # -- exchange over RCCL inside the library (sx_comm.cpp)
+    def comm_prepare(self, cell0, ncells, my_tile, mode):
+        """The non-collective part of comm_init (librccl bound, tile table checked, exchange buffers allocated): raises on
+        THIS rank alone if it cannot be done, so that the ranks can agree before the collective comm_init."""
+        n = len(cell0)
+        L.check(self._lib.sx_comm_prepare(self._h, n, my_tile, (C.c_int32 * n)(*cell0), (C.c_int32 * n)(*ncells), EXCHANGE_MODES[mode]))
+
     def comm_init(self, cell0, ncells, my_tile, mode, unique_id):
         """Collective over all tiles: ncclCommInitRank on this tile's device + exchange buffers. mode "a2a" or "gather"."""
         n = len(cell0)
         c0 = (C.c_int32 * n)(*cell0)
         nc = (C.c_int32 * n)(*ncells)
         assert len(unique_id) == 128
-        L.check(self._lib.sx_comm_init(self._h, n, my_tile, c0, nc, {"a2a": 0, "gather": 1}[mode], bytes(unique_id)))
+        L.check(self._lib.sx_comm_init(self._h, n, my_tile, c0, nc, EXCHANGE_MODES[mode], bytes(unique_id)))
 
     def exchange(self):
         """Halo / shared sum / patch solve of one step on the handle's stream (src/semiimplicit.jl:320-329, 272-285)."""
@@ -432,6 +438,9 @@ class Grid:
         b = C.c_double(0.0)
         L.check(self._lib.sx_kernel_bytes(self._h, name.encode(), C.byref(b)))
         return b.value
+
+
+EXCHANGE_MODES = {"a2a": 0, "gather": 1}
 
 
 def comm_unique_id():

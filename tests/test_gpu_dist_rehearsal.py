@@ -112,6 +112,25 @@ def test_bench_cli_two_ranks_on_one_device():
 
 
 @pytest.mark.gpu
+def test_bench_cli_two_ranks_self_spawned():
+    """`python3 bench.py --gpus 2 ...` exactly as the driver types it, with NO launcher in front: bench.py starts its own two
+    ranks as child processes (before it touches the GPU) and hands back rank 0's contract line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "rlz_small",
+           "--backend", "gloo", "--one-device"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["nan"] is False and d["config"]["tiles"] == 2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("exchange", ["a2a", "gather"])
 @pytest.mark.parametrize("maker,kw", [(cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}), (cases.rl_slab, {"num_cells": 9}),
                                        (cases.rz_semiimplicit, {"num_cells": 9})])
