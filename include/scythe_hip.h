@@ -233,6 +233,24 @@ int sx_a2a_pack_b(sx_handle *h, void *dev_send);
 int sx_a2a_solve(sx_handle *h, const void *dev_recv, void *dev_send);
 int sx_a2a_unpack_a(sx_handle *h, const void *dev_recv);
 
+/* --- interface-only (partitioned) patch solve ---------------------------------------------------------------------------
+ * instead of the redundant whole-patch solve of src/semiimplicit.jl:285 every tile solves its OWN rows
+ * (a chain of n / N rows) and only what couples tiles travels: per tile and column its 6 edge values and the <= 4 rows whose
+ * coefficient another tile owns (the 3 halo rows of src/semiimplicit.jl:320-329, PERIODIC wrap rows) go to the owner of
+ * the column's reduced system, 6 right-hand-side corrections and the <= 4 foreign coefficients come back.  Per step, after
+ * sx_advance:
+ *   1. sx_iface_local     tile-local banded solve of the tile's B rows; its 10 rows -> send buffer [dest d][10][cols of d]
+ *   2. all-to-all         arrive as [tile t][10][my cols]
+ *   3. sx_iface_reduce    one dense [10 N x 10 N] operator per boundary-condition class (built at configure) per column
+ *   4. all-to-all         reverse direction
+ *   5. sx_iface_apply     a = y' + Z c  ->  the patch A rows this tile evaluates
+ * Column split and table arguments as for sx_a2a_*; needs >= 2 tiles with >= 6 free coefficients each. */
+int sx_iface_configure(sx_handle *h, int32_t n_tiles, int32_t my_tile, const int32_t *tile_cell0, const int32_t *tile_num_cells);
+int sx_iface_col_starts(sx_handle *h, int64_t *out /* [n_tiles + 1] */);
+int sx_iface_local(sx_handle *h, void *dev_send);
+int sx_iface_reduce(sx_handle *h, const void *dev_recv, void *dev_send);
+int sx_iface_apply(sx_handle *h, const void *dev_recv);
+
 /* --- exchange over RCCL, inside the library --------------------------------------------------------------------------
  * One process per GPU, one tile per process (src/semiimplicit.jl:179-184).  The reference's per-step exchange - the halo
  * chain tile -> tile + 1 (src/semiimplicit.jl:203-219, 320-329), the shared sum on the master (:272-282) and the patch solve
@@ -244,7 +262,8 @@ int sx_a2a_unpack_a(sx_handle *h, const void *dev_recv);
  *   step  : sx_advance(h, t); sx_exchange(h);                               (replaces :320-329, :272-285)
  * mode 0 = transposed solve (two all-to-alls of B / A rows, each rank solves its share of the columns for the whole
  * patch: scales), mode 1 = the reference's protocol (halo rows to the next tile, all-gather of the owned rows, redundant
- * patch solve).  tile_cell0 / tile_num_cells describe all n tiles (calcTileSizes rows 4 and 3, 0-based cell0).
+ * patch solve), mode 2 = interface-only solve (tile-local solves, two all-to-alls of 10 rows per tile: least traffic and the
+ * shortest recurrence; with one tile it is the plain solve).  tile_cell0 / tile_num_cells describe all n tiles (calcTileSizes rows 4 and 3, 0-based cell0).
  * sx_comm_attach does the same with a communicator the host already owns (ncclComm_t, e.g. from NCCL.jl); it is not
  * destroyed with the handle.  After sx_exchange the patch A coefficients this tile evaluates are in place for the next
  * sx_advance / sx_tile_transform.

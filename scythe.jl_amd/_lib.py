@@ -83,6 +83,11 @@ SYMBOLS = {
     "sx_a2a_pack_b": (C.c_int, [_H, C.c_void_p]),
     "sx_a2a_solve": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
     "sx_a2a_unpack_a": (C.c_int, [_H, C.c_void_p]),
+    "sx_iface_configure": (C.c_int, [_H, C.c_int32, C.c_int32, P_I32, P_I32]),
+    "sx_iface_col_starts": (C.c_int, [_H, P_I64]),
+    "sx_iface_local": (C.c_int, [_H, C.c_void_p]),
+    "sx_iface_reduce": (C.c_int, [_H, C.c_void_p, C.c_void_p]),
+    "sx_iface_apply": (C.c_int, [_H, C.c_void_p]),
     "sx_comm_unique_id": (C.c_int, [C.c_char_p]),
     "sx_comm_prepare": (C.c_int, [_H, C.c_int32, C.c_int32, P_I32, P_I32, C.c_int32]),
     "sx_comm_init": (C.c_int, [_H, C.c_int32, C.c_int32, P_I32, P_I32, C.c_int32, C.c_char_p]),

@@ -19,6 +19,7 @@ void set_error(const std::string &msg) {
 }
 void clear_error() { g_err_set = false; }
 static int status() { return g_err_set ? 1 : 0; }
+int error_status() { return status(); }
 
 #define HIPOK(x)                                                                          \
     do {                                                                                  \
@@ -407,6 +408,8 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
             cls[(size_t)v * 2 + q] = found;
         }
     h->ncls = (int)classes.size();
+    h->classes = classes;
+    h->hcls = cls;
     {
         const int nb = h->b_rDim;
         std::vector<int> cmeta((size_t)h->ncls * 4);
@@ -613,6 +616,7 @@ int sx_destroy(sx_handle *h) {
     dft_phases_dump();
 #endif
     comm_release(h);
+    iface_release(h);
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);

@@ -72,7 +72,8 @@ struct GroupScope {
 struct CommState {
     NcclComm comm = nullptr;
     bool owned = false;            // created by sx_comm_init (destroyed with the handle) vs attached by the host
-    int n = 0, me = 0, mode = -1;  // mode 0: transposed solve (all-to-all), 1: halo + all-gather + redundant solve
+    int n = 0, me = 0, mode = -1;  // mode 0: transposed solve (all-to-all), 1: halo + all-gather + redundant solve,
+                                   // 2: interface-only solve (tile-local solves + all-to-all of 10 rows, sx_iface.hip)
     std::vector<int> cell0, ncells;
     // a2a: tile side [dest d][row][cw[d]], owner side [tile t][row][cw[me]]
     std::vector<int64_t> tile_off, tile_cnt, own_off, own_cnt;
@@ -131,22 +132,26 @@ int sx_comm_unique_id(char *out128) {
 }
 
 static int configure(sx_handle *h, CommState *c, int32_t n, int32_t me, const int32_t *cell0, const int32_t *ncells, int32_t mode) {
-    if (mode != 0 && mode != 1) { set_error("exchange mode must be 0 (all-to-all) or 1 (gather)"); return 1; }
+    if (mode < 0 || mode > 2) { set_error("exchange mode must be 0 (all-to-all), 1 (gather) or 2 (interface-only)"); return 1; }
+    if (mode == 2 && n == 1) mode = 0;          // one tile has no interfaces: the plain patch solve
     // both protocols index patch rows through this table (mode 1 writes a b_rDim-sized offset vector from it, and a tile of
     // fewer than 3 cells would make the halo rows it sends overlap the rows that receive the halo add)
     if (!tile_table_ok(h, n, me, cell0, ncells)) return 1;
     c->n = n; c->me = me; c->mode = mode;
     c->cell0.assign(cell0, cell0 + n);
     c->ncells.assign(ncells, ncells + n);
-    if (mode == 0) {
-        if (sx_a2a_configure(h, n, me, cell0, ncells)) return 1;
+    if (mode == 0 || mode == 2) {
+        // both all-to-all protocols: tile side [dest d][rows of mine][cw[d]], owner side [tile t][rows of t][cw[me]];
+        // mode 0 moves all ncells + 3 rows of a tile, mode 2 its 10 interface rows
         std::vector<int64_t> cs(n + 1);
-        if (sx_a2a_col_starts(h, cs.data())) return 1;
+        if (mode == 0 ? (sx_a2a_configure(h, n, me, cell0, ncells) || sx_a2a_col_starts(h, cs.data()))
+                      : (sx_iface_configure(h, n, me, cell0, ncells) || sx_iface_col_starts(h, cs.data()))) return 1;
         c->tile_off.assign(n, 0); c->tile_cnt.assign(n, 0); c->own_off.assign(n, 0); c->own_cnt.assign(n, 0);
         int64_t to = 0, oo = 0;
         for (int d = 0; d < n; d++) {
-            c->tile_off[d] = to; c->tile_cnt[d] = (int64_t)(ncells[me] + 3) * (cs[d + 1] - cs[d]); to += c->tile_cnt[d];
-            c->own_off[d] = oo; c->own_cnt[d] = (int64_t)(ncells[d] + 3) * (cs[me + 1] - cs[me]); oo += c->own_cnt[d];
+            const int64_t rows_me = mode == 0 ? ncells[me] + 3 : 10, rows_d = mode == 0 ? ncells[d] + 3 : 10;
+            c->tile_off[d] = to; c->tile_cnt[d] = rows_me * (cs[d + 1] - cs[d]); to += c->tile_cnt[d];
+            c->own_off[d] = oo; c->own_cnt[d] = rows_d * (cs[me + 1] - cs[me]); oo += c->own_cnt[d];
         }
         if (!dev_alloc(h, &c->tile_buf, to) || !dev_alloc(h, &c->tile_buf2, to) || !dev_alloc(h, &c->own_in, oo) || !dev_alloc(h, &c->own_out, oo)) return 1;
     } else {
@@ -277,18 +282,20 @@ int sx_exchange_local(sx_handle **hs, int32_t n) {
     }
     for (int t = 0; t < n; t++) hs[t]->stream = s0;
     int rc = 0;
-    if (cs[0]->mode == 0) {
-        for (int t = 0; t < n && !rc; t++) rc = sx_a2a_pack_b(hs[t], cs[t]->tile_buf);
+    if (cs[0]->mode == 0 || cs[0]->mode == 2) {
+        const bool ifc = cs[0]->mode == 2;
+        for (int t = 0; t < n && !rc; t++) rc = ifc ? sx_iface_local(hs[t], cs[t]->tile_buf) : sx_a2a_pack_b(hs[t], cs[t]->tile_buf);
         for (int sdr = 0; sdr < n && !rc; sdr++)          // sender sdr -> receiver d: what ncclSend(sdr, d) / ncclRecv(d, sdr) move
             for (int d = 0; d < n; d++) {
                 if (cs[sdr]->tile_cnt[d] != cs[d]->own_cnt[sdr]) { set_error("exchange geometry mismatch"); rc = 1; break; }
                 if (!copy(cs[d]->own_in + cs[d]->own_off[sdr], cs[sdr]->tile_buf + cs[sdr]->tile_off[d], cs[sdr]->tile_cnt[d], s0)) { set_error("hipMemcpyAsync failed"); rc = 1; break; }
             }
-        for (int t = 0; t < n && !rc; t++) rc = sx_a2a_solve(hs[t], cs[t]->own_in, cs[t]->own_out);
+        for (int t = 0; t < n && !rc; t++)
+            rc = ifc ? sx_iface_reduce(hs[t], cs[t]->own_in, cs[t]->own_out) : sx_a2a_solve(hs[t], cs[t]->own_in, cs[t]->own_out);
         for (int o = 0; o < n && !rc; o++)                // owner o -> tile t
             for (int t = 0; t < n; t++)
                 if (!copy(cs[t]->tile_buf2 + cs[t]->tile_off[o], cs[o]->own_out + cs[o]->own_off[t], cs[o]->own_cnt[t], s0)) { set_error("hipMemcpyAsync failed"); rc = 1; break; }
-        for (int t = 0; t < n && !rc; t++) rc = sx_a2a_unpack_a(hs[t], cs[t]->tile_buf2);
+        for (int t = 0; t < n && !rc; t++) rc = ifc ? sx_iface_apply(hs[t], cs[t]->tile_buf2) : sx_a2a_unpack_a(hs[t], cs[t]->tile_buf2);
     } else {
         const int64_t C = hs[0]->C;
         for (int t = 1; t < n && !rc; t++) {              // halo rows t-1 -> t, then the halo add on t
@@ -325,23 +332,25 @@ int sx_exchange(sx_handle *h) {
     const int n = c->n, me = c->me;
     hipStream_t s = h->stream;
     GroupScope grp(R);
-    if (c->mode == 0) {
-        // transposed solve: B rows -> owners of the column ranges, solve my columns for the whole patch, A rows back
-        if (sx_a2a_pack_b(h, c->tile_buf)) return 1;
+    if (c->mode == 0 || c->mode == 2) {
+        // transposed solve: B rows -> owners of the column ranges, solve my columns for the whole patch, A rows back;
+        // interface-only solve: the same two all-to-alls with 10 rows per tile around the reduced system (sx_iface.hip)
+        const bool ifc = c->mode == 2;
+        if (ifc ? sx_iface_local(h, c->tile_buf) : sx_a2a_pack_b(h, c->tile_buf)) return 1;
         NCCLOK(grp.start());
         for (int d = 0; d < n; d++) {
             NCCLOK(R->Send(c->tile_buf + c->tile_off[d], (size_t)c->tile_cnt[d], NCCL_DOUBLE, d, c->comm, s));
             NCCLOK(R->Recv(c->own_in + c->own_off[d], (size_t)c->own_cnt[d], NCCL_DOUBLE, d, c->comm, s));
         }
         NCCLOK(grp.end());
-        if (sx_a2a_solve(h, c->own_in, c->own_out)) return 1;
+        if (ifc ? sx_iface_reduce(h, c->own_in, c->own_out) : sx_a2a_solve(h, c->own_in, c->own_out)) return 1;
         NCCLOK(grp.start());
         for (int t = 0; t < n; t++) {
             NCCLOK(R->Send(c->own_out + c->own_off[t], (size_t)c->own_cnt[t], NCCL_DOUBLE, t, c->comm, s));
             NCCLOK(R->Recv(c->tile_buf2 + c->tile_off[t], (size_t)c->tile_cnt[t], NCCL_DOUBLE, t, c->comm, s));
         }
         NCCLOK(grp.end());
-        return sx_a2a_unpack_a(h, c->tile_buf2);
+        return ifc ? sx_iface_apply(h, c->tile_buf2) : sx_a2a_unpack_a(h, c->tile_buf2);
     }
     // the reference's protocol: halo rows tile -> tile + 1 (:320-329), owned rows to everybody (:272-282), redundant solve (:285)
     double *mine = c->gbuf + (int64_t)me * c->max_rows * h->C;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 #include "scythe_hip.h"
 
@@ -17,6 +18,9 @@ struct SplineClass {
     double gl[3][2] = {}, gr[3][2] = {};   // dependent boundary coefficients in terms of the first/last two free ones
     std::vector<double> Lband;             // [b_rDim][4]  L[i][i-3..i]
     std::vector<double> Larrow;            // [3][b_rDim]  last three rows of L (periodic only)
+    // kept for the interface-only (partitioned) patch solve, which factors the diagonal blocks of the tiles (sx_iface.hip)
+    std::vector<double> Mdense;                             // [nfree][nfree]  Gamma (P + eps_q Q) Gamma^T before factoring
+    std::vector<std::vector<std::pair<int, double>>> Gam;   // Gamma as sparse rows: free unknown -> (patch row, weight)
 };
 
 struct ChebOps {
@@ -139,6 +143,9 @@ struct sx_handle {
     int *d_flag = nullptr;
     unsigned long long *d_maxabs = nullptr;   // [V] scratch of sx_max_abs
     void *comm_state = nullptr;               // RCCL exchange state (sx_comm.cpp)
+    void *iface_state = nullptr;              // interface-only patch solve (sx_iface.hip)
+    std::vector<sx::SplineClass> classes;     // host copies of the spline classes (d_cls indexes them)
+    std::vector<int> hcls;                    // host copy of d_cls: [v][2] -> class of (k = 0, k >= 1)
     int *d_mask_full = nullptr, *d_mask_eq = nullptr;   // per-variable bit masks of derivative slots to produce
     int mask_eq_bits = 0, mask_full_bits = 0;            // total number of (variable, slot) planes in each mask
     int mask_eq_val = 0, mask_full_val = 0, mask_node_val = 0;   // of which value-slot planes (always fp64)
@@ -192,7 +199,9 @@ void timer_end(sx_handle *h);
 void timers_flush(sx_handle *h);
 void set_error(const std::string &msg);
 void clear_error();
+int error_status();   // 1 if set_error has been called since the last clear_error
 void comm_release(sx_handle *h);
+void iface_release(sx_handle *h);
 bool tile_table_ok(const sx_handle *h, int n, int me, const int32_t *cell0, const int32_t *ncells);
 #ifdef SX_PHASES
 void phases_dump();

@@ -127,6 +127,8 @@ bool build_spline_class(int nc, double DX, double l_q, int bcl, int bcr, SplineC
             A[(size_t)a * n + b] = s;
             A[(size_t)b * n + a] = s;
         }
+    out.Mdense = A;
+    out.Gam = G;
     // dense Cholesky A = L L^T (lower)
     for (int j = 0; j < n; j++) {
         double d = A[(size_t)j * n + j];

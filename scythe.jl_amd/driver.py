@@ -153,9 +153,10 @@ class DistExchange:
 class A2ALayout:
     """Buffer geometry of the transposed solve for tile `me` (see include/scythe_hip.h, sx_a2a_*)."""
 
-    def __init__(self, layout: PatchLayout, col_starts, me):
+    def __init__(self, layout: PatchLayout, col_starts, me, rows=None):
+        """rows = None: every tile moves all its ncells + 3 rows (transposed solve); rows = 10: the interface-only solve."""
         self.n = layout.num_tiles
-        self.rows = [layout.rows(t) for t in range(self.n)]
+        self.rows = [layout.rows(t) if rows is None else rows for t in range(self.n)]
         self.cw = [int(col_starts[d + 1] - col_starts[d]) for d in range(self.n)]
         self.me = me
         # tile side: [dest d][row][cw[d]];  owner side: [tile t][row][cw[me]]
@@ -165,16 +166,30 @@ class A2ALayout:
         self.owner_elems = sum(self.owner_split)
 
 
-class LocalA2AExchange:
-    """Transposed solve with all tiles in this process (single-GPU test of the pack / solve / unpack kernels)."""
+IFACE_ROWS = 10     # rows per tile that travel in the interface-only solve (6 edge values + 4 foreign rows, sx_iface.hip)
 
-    def __init__(self, layout: PatchLayout, tiles, device):
+
+def _kernels_of(tile, kind):
+    """(first, middle, last) device stages around the two all-to-alls: pack / solve / unpack of the transposed solve or
+    local solve / reduced system / correction of the interface-only solve."""
+    if kind == "iface":
+        return tile.iface_local, tile.iface_reduce, tile.iface_apply
+    return tile.a2a_pack_b, tile.a2a_solve, tile.a2a_unpack_a
+
+
+class LocalA2AExchange:
+    """Transposed solve (kind "a2a") or interface-only solve (kind "iface") with all tiles in this process (single-GPU test
+    of the kernels on either side of the two all-to-alls)."""
+
+    def __init__(self, layout: PatchLayout, tiles, device, kind="a2a"):
         torch = _torch()
-        self.tiles = tiles
+        self.tiles, self.kind = tiles, kind
         self.lay = []
         for t, g in enumerate(tiles):
-            cs = g.a2a_configure(layout.cell0, layout.ncells, t)
-            self.lay.append(A2ALayout(layout, cs, t))
+            if kind == "iface":
+                self.lay.append(A2ALayout(layout, g.iface_configure(layout.cell0, layout.ncells, t), t, rows=IFACE_ROWS))
+            else:
+                self.lay.append(A2ALayout(layout, g.a2a_configure(layout.cell0, layout.ncells, t), t))
         z = lambda n: torch.zeros(max(n, 1), dtype=torch.float64, device=device)
         self.tile_buf = [z(l.tile_elems) for l in self.lay]      # pack output / unpack input
         self.own_in = [z(l.owner_elems) for l in self.lay]
@@ -192,27 +207,28 @@ class LocalA2AExchange:
 
     def exchange_and_solve(self):
         for g, b in zip(self.tiles, self.tile_buf):
-            g.a2a_pack_b(b.data_ptr())
+            _kernels_of(g, self.kind)[0](b.data_ptr())
         self._all_to_all(self.tile_buf, [l.tile_split for l in self.lay], self.own_in, [l.owner_split for l in self.lay])
         for g, i, o in zip(self.tiles, self.own_in, self.own_out):
-            g.a2a_solve(i.data_ptr(), o.data_ptr())
+            _kernels_of(g, self.kind)[1](i.data_ptr(), o.data_ptr())
         self._all_to_all(self.own_out, [l.owner_split for l in self.lay], self.tile_buf, [l.tile_split for l in self.lay])
         for g, b in zip(self.tiles, self.tile_buf):
-            g.a2a_unpack_a(b.data_ptr())
+            _kernels_of(g, self.kind)[2](b.data_ptr())
 
 
 class DistA2AExchange:
-    """Transposed solve, one tile per rank: two all_to_all_single calls per step (RCCL over xGMI on the GPU box)."""
+    """Transposed solve (kind "a2a") or interface-only solve (kind "iface"), one tile per rank: two all_to_all_single calls
+    per step (RCCL over xGMI on the GPU box)."""
 
-    def __init__(self, layout: PatchLayout, tile, device, group=None, col_starts=None):
+    def __init__(self, layout: PatchLayout, tile, device, group=None, col_starts=None, kind="a2a"):
         torch = _torch()
         import torch.distributed as dist
-        self.dist, self.group, self.tile = dist, group, tile
+        self.dist, self.group, self.tile, self.kind = dist, group, tile, kind
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         assert self.world == layout.num_tiles
         if tile is not None:
-            col_starts = tile.a2a_configure(layout.cell0, layout.ncells, self.rank)
-        self.lay = A2ALayout(layout, col_starts, self.rank)
+            col_starts = (tile.iface_configure if kind == "iface" else tile.a2a_configure)(layout.cell0, layout.ncells, self.rank)
+        self.lay = A2ALayout(layout, col_starts, self.rank, rows=IFACE_ROWS if kind == "iface" else None)
         z = lambda n: torch.zeros(max(n, 1), dtype=torch.float64, device=device)
         self.tile_buf, self.tile_buf2 = z(self.lay.tile_elems), z(self.lay.tile_elems)
         self.own_in, self.own_out = z(self.lay.owner_elems), z(self.lay.owner_elems)
@@ -221,6 +237,7 @@ class DistA2AExchange:
         self.stage_host = (dist.get_backend(group) == "gloo" and self.tile_buf.is_cuda)
 
     def _a2a(self, out, inp, out_split, in_split):
+        out, inp = out[:sum(out_split)], inp[:sum(in_split)]        # a rank without columns keeps a 1-element placeholder buffer
         if self.stage_host:
             o = out.cpu()
             self.dist.all_to_all_single(o, inp.cpu(), out_split, in_split, group=self.group)
@@ -231,11 +248,12 @@ class DistA2AExchange:
     def exchange_and_solve(self, pack=None, solve=None, unpack=None):
         """pack / solve / unpack default to the tile's device kernels; the CPU tests pass numpy stand-ins."""
         lay = self.lay
-        (pack or (lambda b: self.tile.a2a_pack_b(b.data_ptr())))(self.tile_buf)
+        k = _kernels_of(self.tile, self.kind) if self.tile is not None else (None, None, None)
+        (pack or (lambda b: k[0](b.data_ptr())))(self.tile_buf)
         self._a2a(self.own_in, self.tile_buf, lay.owner_split, lay.tile_split)
-        (solve or (lambda i, o: self.tile.a2a_solve(i.data_ptr(), o.data_ptr())))(self.own_in, self.own_out)
+        (solve or (lambda i, o: k[1](i.data_ptr(), o.data_ptr())))(self.own_in, self.own_out)
         self._a2a(self.tile_buf2, self.own_out, lay.tile_split, lay.owner_split)
-        (unpack or (lambda b: self.tile.a2a_unpack_a(b.data_ptr())))(self.tile_buf2)
+        (unpack or (lambda b: k[2](b.data_ptr())))(self.tile_buf2)
 
 
 class LibExchange:
@@ -300,8 +318,9 @@ class ModelRun:
 
     def __init__(self, model: ModelParameters, num_tiles=1, rank=None, device=None, use_dist=False, exchange="a2a",
                  split="reference", impl="torch", unique_id=None):
-        """exchange: "a2a" = transposed solve over all-to-all (scales), "gather" = the reference's protocol
-        (halo chain + gather of owned rows + redundant patch solve on every tile).
+        """exchange: "a2a" = transposed solve over all-to-all, "iface" = interface-only solve (tile-local solves, all-to-all of
+        10 rows per tile around a small reduced system: least traffic, shortest recurrence), "gather" = the reference's
+        protocol (halo chain + gather of owned rows + redundant patch solve on every tile).
         impl (use_dist only): "lib" = RCCL calls inside libscythe_hip.so on the tile's stream (sx_exchange; also valid with
         ONE tile, where every send is a send to self - the one-GPU self-test of that code path), "torch" =
         torch.distributed collectives on device tensors (also what the gloo rehearsals use)."""
@@ -330,14 +349,14 @@ class ModelRun:
             self.impl = "lib"
             self.exchange = LocalLibExchange(self.layout, self.tiles, exchange)
         elif num_tiles > 1:
-            if exchange == "a2a":
-                self.exchange = (DistA2AExchange(self.layout, self.tiles[0], device) if use_dist
-                                 else LocalA2AExchange(self.layout, self.tiles, device))
+            if exchange in ("a2a", "iface"):
+                self.exchange = (DistA2AExchange(self.layout, self.tiles[0], device, kind=exchange) if use_dist
+                                 else LocalA2AExchange(self.layout, self.tiles, device, kind=exchange))
             elif exchange == "gather":
                 self.exchange = (DistExchange(self.layout, self.tiles[0], device) if use_dist
                                  else LocalExchange(self.layout, self.tiles, device))
             else:
-                raise ValueError("exchange must be 'a2a' or 'gather'")
+                raise ValueError("exchange must be 'a2a', 'iface' or 'gather'")
         self.t = 0
 
     def _bind_streams(self, device):
@@ -378,7 +397,7 @@ class ModelRun:
         if self.impl == "lib":
             self.exchange.exchange_and_solve()
             return
-        if self.exchange_kind == "a2a":
+        if self.exchange_kind in ("a2a", "iface"):
             self.exchange.exchange_and_solve()
             return
         if self.exchange is not None:
@@ -406,7 +425,7 @@ class ModelRun:
         coefficients [s_patch, V].  With the reference's protocol every tile holds the whole patch; with the transposed solve a
         tile only holds the rows it evaluates, so the patch array is assembled from every tile's OWNED rows (output cadence
         only; one process per GPU: gathered to rank 0, other ranks return None)."""
-        if self.exchange_kind != "a2a":
+        if self.exchange_kind not in ("a2a", "iface"):
             return self.tiles[0].patchSpectral
         nb = self.layout.b_rDim
         parts = []

@@ -387,6 +387,23 @@ class Grid:
     def a2a_unpack_a(self, dev_recv):
         L.check(self._lib.sx_a2a_unpack_a(self._h, C.c_void_p(dev_recv)))
 
+    # -- interface-only (partitioned) patch solve (sx_iface.hip): same call pattern as the transposed solve, 10 rows per tile
+    def iface_configure(self, cell0, ncells, my_tile):
+        n = len(cell0)
+        L.check(self._lib.sx_iface_configure(self._h, n, my_tile, (C.c_int32 * n)(*cell0), (C.c_int32 * n)(*ncells)))
+        cs = np.zeros(n + 1, dtype=np.int64)
+        L.check(self._lib.sx_iface_col_starts(self._h, cs.ctypes.data_as(L.P_I64)))
+        return cs
+
+    def iface_local(self, dev_send):
+        L.check(self._lib.sx_iface_local(self._h, C.c_void_p(dev_send)))
+
+    def iface_reduce(self, dev_recv, dev_send):
+        L.check(self._lib.sx_iface_reduce(self._h, C.c_void_p(dev_recv), C.c_void_p(dev_send)))
+
+    def iface_apply(self, dev_recv):
+        L.check(self._lib.sx_iface_apply(self._h, C.c_void_p(dev_recv)))
+
     def index_maps(self):
         """calcPatchMap / calcHaloMap (src/semiimplicit.jl:79-86): 1-based linear indices into one variable's column:
         (patch_owned, tile_owned, patch_halo, tile_halo)."""
@@ -440,7 +457,7 @@ class Grid:
         return b.value
 
 
-EXCHANGE_MODES = {"a2a": 0, "gather": 1}
+EXCHANGE_MODES = {"a2a": 0, "gather": 1, "iface": 2}
 
 
 def comm_unique_id():

@@ -204,8 +204,8 @@ class HipModel:
 
     @property
     def A(self):
-        if self.run.exchange_kind == "a2a":
-            return None          # no tile holds the whole patch in the transposed solve
+        if self.run.exchange_kind in ("a2a", "iface"):
+            return None          # no tile holds the whole patch in the transposed / interface-only solve
         return self.run.tiles[0].patchSpectral
 
 

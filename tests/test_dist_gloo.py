@@ -170,3 +170,105 @@ def test_all_to_all_transpose_layout(case_name, world):
     res = dict(q.get(timeout=5) for _ in range(world))
     assert sorted(res) == list(range(world))
     assert max(res.values()) < 1e-14
+
+
+# ----------------------------------------------------------------------------- interface-only solve
+def _iface_worker(rank, world, port, case_name, num_cells, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.partitioned_np import InterfaceSolve
+        case = getattr(cases, case_name)(num_cells=num_cells)
+        gp, _ = cases.hip_params(case)
+        g = cases.oracle_grid(case)
+        K2, G = g.K2, g.V * g.b_zDim
+        n_cols = G * K2
+        lay = S.PatchLayout(gp, world, n_cols=n_cols)
+        col_starts = np.array([(G * d // world) * K2 for d in range(world + 1)], dtype=np.int64)   # rule of sx_iface_configure
+        pts = g.gridpoints().reshape(-1, 1 + g.has_l + g.has_z)
+        vals = case["ic"](pts)
+        shared = np.zeros((g.S_patch(), g.V), order="F")
+        mine, p0 = None, 0
+        for t in range(world):
+            tl = OC.TileOracle(g, lay.cell0[t], lay.ncells[t])
+            b = tl.forward(vals[p0:p0 + tl.N])
+            p0 += tl.N
+            tl.add_to_shared(b, shared)
+            if t == rank:
+                mine = _to_rows(g, b, tl.og.K2t, lay.rows(t))
+                mytile = tl
+        # expected: the reference's protocol - shared sum, then the one-patch solve (src/semiimplicit.jl:272-285)
+        expected = _patch_rows(g, np.asfortranarray(mytile.spline_solve(shared)))
+        # boundary-condition class of every column, one numpy interface solver per class
+        cls_of, keys = np.zeros(n_cols, dtype=np.int64), []
+        for v, name in enumerate(g.names):
+            for zm in range(g.b_zDim):
+                for blk in range(K2):
+                    key = (g.BCL_k0[name] if blk == 0 else g.BCL[name], g.BCR[name])
+                    if key not in keys:
+                        keys.append(key)
+                    cls_of[(v * g.b_zDim + zm) * K2 + blk] = keys.index(key)
+        solvers = {i: InterfaceSolve(g.spline(*key), lay.cell0, lay.ncells) for i, key in enumerate(keys)}
+        ex = S.DistA2AExchange(lay, None, "cpu", col_starts=col_starts, kind="iface")
+        R = S.driver.IFACE_ROWS
+        c0, c1 = col_starts[rank], col_starts[rank + 1]
+        yprime = {}
+
+        def local(buf):
+            send = np.zeros((R, n_cols))
+            for k, ps in solvers.items():
+                cols = np.flatnonzero(cls_of == k)
+                yprime[k], send[:, cols] = ps.local(rank, mine[:, cols])
+            buf[:] = torch.from_numpy(np.concatenate([send[:, col_starts[d]:col_starts[d + 1]].ravel() for d in range(world)]))
+
+        def reduce_(inp, out):
+            w = c1 - c0
+            x = inp.numpy()[:world * R * w].reshape(world, R, w)     # a rank without columns holds a 1-element placeholder
+            y = np.zeros_like(x)
+            for k, ps in solvers.items():
+                cols = np.flatnonzero(cls_of[c0:c1] == k)
+                if len(cols):
+                    y[:, :, cols] = ps.reduce(x[:, :, cols])
+            out[:y.size] = torch.from_numpy(y.ravel())
+
+        got = {}
+
+        def apply_(buf):
+            recv = np.zeros((R, n_cols))
+            o = 0
+            for d in range(world):
+                w = col_starts[d + 1] - col_starts[d]
+                recv[:, col_starts[d]:col_starts[d + 1]] = buf[o:o + R * w].numpy().reshape(R, w)
+                o += R * w
+            rows = np.zeros((lay.rows(rank), n_cols))
+            for k, ps in solvers.items():
+                cols = np.flatnonzero(cls_of == k)
+                rows[:, cols] = ps.apply(rank, yprime[k], recv[:, cols])
+            got["rows"] = rows
+
+        ex.exchange_and_solve(pack=local, solve=reduce_, unpack=apply_)
+        want = expected[lay.cell0[rank]:lay.cell0[rank] + lay.rows(rank)]
+        q.put((rank, float(np.abs(got["rows"] - want).max() / np.abs(expected).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case_name,num_cells,world", [("rl_slab", 14, 2), ("rlz_hrbl", 36, 3), ("kat_r", 40, 3)])
+def test_interface_only_solve_over_all_to_all(case_name, num_cells, world):
+    """The interface-only patch solve across ranks (gloo): every rank solves its own tile's rows, the uneven
+    all_to_all_single splits carry 10 rows per tile to the owner of each column range and back, and every tile ends up
+    with exactly the A rows the reference's shared sum + one-patch solve gives it (the device stages of sx_iface.hip are
+    stood in for by their numpy statement, oracle/partitioned_np.py; PERIODIC wrap rows with kat_r)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_iface_worker, args=(r, world, port, case_name, num_cells, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert sorted(res) == list(range(world))
+    assert max(res.values()) < 1e-11

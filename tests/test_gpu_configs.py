@@ -98,10 +98,11 @@ def _bench_model(num_tiles, exchange="a2a", split="reference", workload="rlz_513
 def test_config4_full_size_tiling_invariance():
     """RLZ 513 x 256 x 64, 6 variables: 3 even radial tiles and 4 cost-balanced ones (transposed solve, Python-side stand-in
     for the exchange), and 8 cost-balanced tiles with the exchange done INSIDE the library (the RCCL path's buffers and
-    offset tables through the loopback transport, both protocols) reproduce the one-tile run."""
+    offset tables through the loopback transport, all three protocols incl. the interface-only solve) reproduce the one-tile run."""
     fields = []
     for nt, split, impl, exch in ((1, "reference", "torch", "a2a"), (3, "reference", "torch", "a2a"), (4, "cost", "torch", "a2a"),
-                                  (8, "cost", "lib", "a2a"), (8, "cost", "lib", "gather")):
+                                  (8, "cost", "lib", "a2a"), (8, "cost", "lib", "gather"), (8, "cost", "lib", "iface"),
+                                  (4, "reference", "torch", "iface")):
         run = _bench_model(nt, split=split, impl=impl, exchange=exch)
         for _ in range(3):
             run.step()

@@ -143,6 +143,33 @@ def test_tiles_on_one_gpu_match_single_patch_oracle(maker, kw, ntiles, exchange,
     assert _run(case, 4, num_tiles=ntiles, exchange=exchange, impl=impl) < TOL
 
 
+@pytest.mark.parametrize("maker,kw,ntiles", [(cases.rlz_hrbl, {"num_cells": 24, "zDim": 32, "ring_L": 16}, 3),
+                                             (cases.rlz_hrbl, {"num_cells": 20, "zDim": 10}, 2),            # native ragged rings
+                                             (cases.kat_r, {}, 2), (cases.kat_r, {}, 3), (cases.kat_r, {}, 8),   # PERIODIC: wrap-around rows
+                                             (cases.rl_slab, {"num_cells": 20}, 2), (cases.rl_slab, {"num_cells": 31}, 4),
+                                             (cases.rz_semiimplicit, {"num_cells": 21}, 3),
+                                             (cases.r_bcs, {"bcl": "R0", "bcr": "R0", "num_cells": 40}, 4),
+                                             (cases.r_bcs, {"bcl": "R1T0", "bcr": "R1T1", "num_cells": 40}, 4),
+                                             (cases.r_bcs, {"bcl": "R1T2", "bcr": "R2T10", "num_cells": 40}, 3),
+                                             (cases.r_bcs, {"bcl": "R2T20", "bcr": "R3", "num_cells": 40}, 4),
+                                             (cases.r_bcs, {"bcl": "R3", "bcr": "R1T0", "num_cells": 64}, 8)])
+@pytest.mark.parametrize("impl", ["torch", "lib"])
+def test_interface_only_solve_on_tiles_matches_single_patch_oracle(maker, kw, ntiles, impl):
+    """The interface-only ("partitioned") patch solve - every tile solves its own rows, 10 rows per tile and column go
+    through a reduced system (sx_iface.hip; SURVEY.md 8(e)(i), replacing the redundant whole-patch solve of
+    src/semiimplicit.jl:285) - against the ONE-patch oracle: every radial boundary-condition class incl. PERIODIC, 2 to 8
+    tiles, even and uneven, through the Python-side all-to-all stand-in and through sx_exchange's own buffers (loopback)."""
+    case = maker(**kw)
+    assert _run(case, 4, num_tiles=ntiles, exchange="iface", impl=impl) < TOL
+
+
+def test_interface_only_solve_refuses_tiles_that_are_too_small():
+    import scythe_jl_amd as S
+    case = cases.rl_slab(num_cells=9)
+    with pytest.raises(S.ScytheHipError, match="fewer than 6 free spline coefficients"):
+        cases.HipModel(case, num_tiles=3, exchange="iface", impl="lib")
+
+
 def test_check_nan_sees_a_nan_on_the_node_space_path():
     """checkCFL: a NaN planted in an outer ring (whose `physical` planes the node-space path never writes during
     sx_advance) must be reported after the next step; a clean run reports nothing."""

@@ -179,11 +179,11 @@ def test_output_time_tag_is_julias_string_of_round_t_2():
 
 
 def test_partitioned_interface_only_patch_solve_equals_the_patch_solve():
-    """Prototype of the SPIKE-type B -> A solve for radial tiles (scythe_jl_amd.partitioned_solve): every tile
+    """Numpy statement of the SPIKE-type B -> A solve for radial tiles (oracle/partitioned_np.py): every tile
     solves its own rows, 6 interface unknowns per tile boundary are exchanged - against the one-patch Cholesky solve of the
     reference's matrix (src/semiimplicit.jl:285 via Springsteel SAtransform), all radial boundary-condition classes."""
     from oracle import oracle_np as O
-    from scythe_jl_amd.partitioned_solve import PartitionedBandedSolve
+    from oracle.partitioned_np import PartitionedBandedSolve
     import scythe_jl_amd as S
     rng = np.random.default_rng(5)
     for bcl, bcr in (("R0", "R0"), ("R1T0", "R1T1"), ("R1T1", "R0"), ("R2T10", "R1T0"), ("R3", "R0"), ("PERIODIC", "PERIODIC")):
@@ -200,3 +200,29 @@ def test_partitioned_interface_only_patch_solve_equals_the_patch_solve():
             wrap = 6 if bcl == "PERIODIC" else 0
             assert len(ps.I) == 6 * (N - 1) + wrap, (bcl, N, len(ps.I))
             assert max(ps.sends) <= 6 and max(ps.needs) <= 6 + wrap
+
+
+def test_staged_interface_solve_equals_the_patch_solve():
+    """The staged form the device runs (oracle/partitioned_np.InterfaceSolve: tile rows in, 10 rows per tile through the reduced
+    system, tile rows out; halo rows and PERIODIC wrap rows travel as foreign rows) against the one-patch solve on the summed
+    B rows (src/semiimplicit.jl:320-329, 285), every radial boundary-condition class, even and uneven tiles."""
+    from oracle import oracle_np as O
+    from oracle.partitioned_np import InterfaceSolve
+    rng = np.random.default_rng(11)
+    for bcl, bcr in (("R0", "R0"), ("R1T0", "R1T1"), ("R1T2", "R2T10"), ("R2T20", "R3"), ("R3", "R1T0"), ("PERIODIC", "PERIODIC")):
+        for cells in ((20, 20), (9, 7, 8, 16), (12, 6, 6, 6, 6, 6, 6, 12)):
+            nc = sum(cells)
+            sp = O.Spline1D(0.0, 3.0e5, nc, bcl=bcl, bcr=bcr)
+            cell0 = [sum(cells[:t]) for t in range(len(cells))]
+            Bt = [rng.standard_normal((n + 3, 5)) for n in cells]            # every tile's own rows incl. its 3 halo rows
+            shared = np.zeros((nc + 3, 5))
+            for c0, b in zip(cell0, Bt):
+                shared[c0:c0 + len(b)] += b
+            ref = sp.SA(shared)
+            ps = InterfaceSolve(sp, cell0, list(cells))
+            loc = [ps.local(t, Bt[t]) for t in range(len(cells))]
+            out = ps.reduce(np.stack([s for _, s in loc]))
+            for t, (y, _) in enumerate(loc):
+                got = ps.apply(t, y, out[t])
+                want = ref[cell0[t]:cell0[t] + cells[t] + 3]
+                assert np.abs(got - want).max() <= 1e-11 * np.abs(ref).max(), (bcl, bcr, cells, t)
