@@ -39,7 +39,7 @@ constexpr int IF_E = 6, IF_X = 4, IF_R = IF_E + IF_X;      // edge values + fore
 constexpr int IF_META = 8;                                  // per class: nt, rowbase, nlead, ntrail, xrow[4]
 
 struct IfaceState {
-    int n = 0, me = 0, g0 = 0, g1 = 0;
+    int n = 0, me = 0, g0 = 0, g1 = 0, nt_max = 0;
     std::vector<int64_t> colstart;                          // [n + 1]
     int *d_meta = nullptr, *d_owner = nullptr;
     int64_t *d_soff = nullptr, *d_cw = nullptr, *d_cs = nullptr;
@@ -160,7 +160,78 @@ __device__ __forceinline__ void iface_local_columns(const double *__restrict__ B
 #undef YSET
 }
 
+// The same for tiles of at most NT unknowns (the case that matters: 8 GPUs share 171 cells): EVERY right-hand-side row of
+// the lane is requested in one burst and the whole recurrence runs in registers - one memory round trip for the loads, one
+// burst of stores; the memory-resident form above pays a round trip per batch of 8 rows, twice (y' is re-read for the back
+// substitution), which is all of its run time at this size.
+template <class T, int NT>
+__device__ __forceinline__ void iface_local_regs(const double *__restrict__ B, double *__restrict__ Y, double *__restrict__ send,
+                                                 int64_t cwd, const int *__restrict__ meta, const double *__restrict__ gl,
+                                                 const double *__restrict__ gr, const double *Lf, int nbt, int64_t C,
+                                                 int64_t col, bool active) {
+    const int nt = meta[0], rb = meta[1], nlead = meta[2], ntrail = meta[3];
+    T *tp = nullptr;
+    T y[NT], xv[IF_X];
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) y[i] = i < nt ? ldp(B + (int64_t)(rb + i) * C + col, tp) : zerop(tp);
+    }
+    // factor rows through LDS (requested behind the right-hand sides, arrive before them): as scalar loads they came in
+    // batches of a few rows, each batch a round trip to L2 on the critical path of the recurrence
+    extern __shared__ double sfac[];                 // [nt + 3][4]
+    for (int e = threadIdx.x; e < (nt + 3) * 4; e += blockDim.x) sfac[e] = Lf[e];
+    __syncthreads();
+    if (!active) return;
+    Lf = sfac;
+#pragma unroll
+    for (int s = 0; s < IF_X; s++) { const int xr = meta[4 + s]; xv[s] = xr >= 0 ? ldp(B + (int64_t)xr * C + col, tp) : zerop(tp); }
+    T bl0 = zerop(tp), bl1 = zerop(tp), br0 = zerop(tp), br1 = zerop(tp);
+    for (int q = 0; q < nlead; q++) { const T b = ldp(B + (int64_t)q * C + col, tp); bl0 = bl0 + gl[q * 2] * b; bl1 = bl1 + gl[q * 2 + 1] * b; }
+    for (int q = 0; q < ntrail; q++) { const T b = ldp(B + (int64_t)(nbt - 1 - q) * C + col, tp); br0 = br0 + gr[q * 2] * b; br1 = br1 + gr[q * 2 + 1] * b; }
+    y[0] = y[0] + bl0;
+    y[1] = y[1] + bl1;
+    T y1 = zerop(tp), y2 = zerop(tp), y3 = zerop(tp);
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        if (i < nt) {
+            T s = y[i];
+            if (i == nt - 2) s = s + br1;
+            if (i == nt - 1) s = s + br0;
+            s = s - (Lf[i * 4 + 2] * y1 + Lf[i * 4 + 1] * y2 + Lf[i * 4 + 0] * y3);
+            s = Lf[i * 4 + 3] * s;
+            y3 = y2; y2 = y1; y1 = s;
+            y[i] = s;
+        }
+    }
+    T x1 = zerop(tp), x2 = zerop(tp), x3 = zerop(tp);
+    T e[IF_E];
+#pragma unroll
+    for (int j = 0; j < IF_E; j++) e[j] = zerop(tp);
+#pragma unroll
+    for (int i = NT - 1; i >= 0; i--) {
+        if (i < nt) {
+            T s = y[i];
+            // rows nt .. nt + 2 of the factor array are zero (build_class_ops pads them), so the three-term form holds for every row
+            s = s - (Lf[(i + 1) * 4 + 2] * x1 + Lf[(i + 2) * 4 + 1] * x2 + Lf[(i + 3) * 4 + 0] * x3);
+            s = Lf[i * 4 + 3] * s;
+            x3 = x2; x2 = x1; x1 = s;
+            stp(Y + (int64_t)(rb + i) * C + col, s);
+            if (i == nt - 1) e[5] = s;
+            if (i == nt - 2) e[4] = s;
+            if (i == nt - 3) e[3] = s;
+            if (i < 3) e[i] = s;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < IF_E; j++) stp(send + (int64_t)j * cwd, e[j]);
+#pragma unroll
+    for (int s = 0; s < IF_X; s++) stp(send + (int64_t)(IF_E + s) * cwd, xv[s]);
+}
+
+constexpr int IF_NT_REGS = 32;     // tiles with at most this many unknowns take the register-resident kernels
+
 // grid: x = waves of 64 wavenumbers + one block for the k = 0 column, y = (variable, z-mode) group; block = 64
+template <bool REGS>
 __global__ void __launch_bounds__(64)
 k_iface_local(const double *__restrict__ B, double *__restrict__ Y, double *__restrict__ send, const int *__restrict__ owner,
               const int64_t *__restrict__ soff, const int64_t *__restrict__ cw, const int64_t *__restrict__ cs,
@@ -173,76 +244,160 @@ k_iface_local(const double *__restrict__ B, double *__restrict__ Y, double *__re
     const bool act = k0 ? threadIdx.x == 0 : 2 * k + 1 < K2;
     const int64_t col = (int64_t)g * K2 + (k0 ? 0 : (act ? 2 * k : 2));
     double *sp = send + soff[d] + (col - cs[d]);
-    if (k0)
-        iface_local_columns<P1, 8>(B, Y, sp, cw[d], meta + c * IF_META, gl + c * 6, gr + c * 6, Lf + (int64_t)c * nbt * 4, nbt, C, col, act);
-    else
-        iface_local_columns<P2, 8>(B, Y, sp, cw[d], meta + c * IF_META, gl + c * 6, gr + c * 6, Lf + (int64_t)c * nbt * 4, nbt, C, col, act);
+    const double *Lc = Lf + (int64_t)c * (nbt + 3) * 4;
+    if (REGS) {
+        if (k0) iface_local_regs<P1, IF_NT_REGS>(B, Y, sp, cw[d], meta + c * IF_META, gl + c * 6, gr + c * 6, Lc, nbt, C, col, act);
+        else iface_local_regs<P2, IF_NT_REGS>(B, Y, sp, cw[d], meta + c * IF_META, gl + c * 6, gr + c * 6, Lc, nbt, C, col, act);
+    } else {
+        if (k0) iface_local_columns<P1, 8>(B, Y, sp, cw[d], meta + c * IF_META, gl + c * 6, gr + c * 6, Lc, nbt, C, col, act);
+        else iface_local_columns<P2, 8>(B, Y, sp, cw[d], meta + c * IF_META, gl + c * 6, gr + c * 6, Lc, nbt, C, col, act);
+    }
 }
 
-// out = Q_class in, per column of this rank's share: in / out [tile][IF_R][cwm].
-// grid: x = my (variable, z-mode) groups, y = output tile; the two classes' Q rows of that tile sit in LDS.
-__global__ void __launch_bounds__(256)
-k_iface_reduce(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ Q, const int *__restrict__ cls,
-               int g0, int Zb, int K2, int64_t cwm, int RN) {
-    extern __shared__ double sq[];                  // [2][IF_R][RN]
-    const int g = g0 + blockIdx.x, v = g / Zb, to = blockIdx.y;
-    for (int q = 0; q < 2; q++) {
-        const double *Qc = Q + ((int64_t)cls[v * 2 + q] * RN + (int64_t)to * IF_R) * RN;
-        for (int e = threadIdx.x; e < IF_R * RN; e += blockDim.x) sq[q * IF_R * RN + e] = Qc[e];
-    }
-    __syncthreads();
-    for (int blk = threadIdx.x; blk < K2; blk += blockDim.x) {
-        const int64_t j = (int64_t)blockIdx.x * K2 + blk;
-        const double *qs = sq + (blk == 0 ? 0 : IF_R * RN);
-        double acc[IF_R];
+// out = Q_class in, per column of this rank's share: in / out [tile][IF_R][cwm]; Qt = Q transposed, [class][input i][RNp outputs],
+// RNp = RN rounded up to 16.  This is a plain dense product Out[RN x cols] = Q[RN x RN] In[RN x cols] (6,400 multiply-adds per
+// column at N = 8) and runs on the f64 matrix cores: a wave owns 16 columns, its In fragments are requested in one burst,
+// the operator fragments come from L2 per 16-row output tile (the scheme of k_colmat_mfma).  Operator entries fed from LDS
+// broadcasts or from scalar loads both left the kernel waiting for its operands (0.03 ms for 8,256 columns).
+// The k = 0 column of a group has its own boundary-condition class: the blocks behind the first ng * nchunk take one each,
+// a thread per output; the 16-column tile that contains it skips that column.
+typedef double iface_d4 __attribute__((ext_vector_type(4)));
+template <int KS>                    // K steps of 4: K = RN <= 4 KS (KS = 20: up to 8 tiles, the operator fragments of the next
+__global__ void __launch_bounds__(256)   // output tile are requested before the current tile's MFMA chain; KS = 40: up to 16)
+k_iface_reduce(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ Qt, const int *__restrict__ cls,
+               int g0, int ng, int nchunk, int Zb, int K2, int64_t cwm, int RN, int RNp) {
+    if ((int)blockIdx.x >= ng * nchunk) {                       // the k = 0 column of group gl_: thread o = output o
+        const int gl_ = blockIdx.x - ng * nchunk, v = (g0 + gl_) / Zb;
+        const double *Qc = Qt + (int64_t)cls[v * 2 + 0] * RN * RNp;
+        const int64_t j = (int64_t)gl_ * K2;
+        __shared__ double sx_in[4 * KS];
+        for (int i = threadIdx.x; i < 4 * KS; i += blockDim.x) sx_in[i] = i < RN ? in[(int64_t)i * cwm + j] : 0.0;
+        __syncthreads();
+        for (int o = threadIdx.x; o < RN; o += blockDim.x) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i0 = 0; i0 < RN; i0 += 20) {               // RN is a multiple of 10: 20 independent operator loads per batch
+                double q[20];
 #pragma unroll
-        for (int o = 0; o < IF_R; o++) acc[o] = 0.0;
-        for (int i = 0; i < RN; i++) {
-            const double x = in[(int64_t)i * cwm + j];
+                for (int u = 0; u < 20; u++) q[u] = (i0 + u < RN) ? Qc[(int64_t)(i0 + u) * RNp + o] : 0.0;
 #pragma unroll
-            for (int o = 0; o < IF_R; o++) acc[o] += qs[o * RN + i] * x;
+                for (int u = 0; u < 20; u++) acc[u & 3] = __builtin_fma(q[u], sx_in[i0 + u], acc[u & 3]);
+            }
+            out[(int64_t)o * cwm + j] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         }
+        return;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 15, kk = lane >> 4;
+    const int gl_ = blockIdx.x / nchunk, chunk = blockIdx.x - gl_ * nchunk, v = (g0 + gl_) / Zb;
+    const int blk0 = (chunk * 4 + wave) * 16;
+    if (blk0 >= K2) return;
+    const int blk = min(blk0 + n, K2 - 1);
+    const int64_t j = (int64_t)gl_ * K2 + blk;
+    const double *Qc = Qt + (int64_t)cls[v * 2 + 1] * RN * RNp;
+    const int ksteps = (RN + 3) / 4;
+    double b[KS], a[KS], an[KS];
 #pragma unroll
-        for (int o = 0; o < IF_R; o++) out[((int64_t)to * IF_R + o) * cwm + j] = acc[o];
+    for (int ks = 0; ks < KS; ks++) {
+        const int k = 4 * ks + kk;
+        b[ks] = (ks < ksteps && k < RN) ? in[(int64_t)k * cwm + j] : 0.0;
+    }
+    auto load_a = [&](double *dst, int t) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int k = 4 * ks + kk;
+            dst[ks] = (ks < ksteps && k < RN) ? Qc[(int64_t)k * RNp + t * 16 + n] : 0.0;
+        }
+    };
+    const bool okc = blk0 + n < K2 && blk0 + n >= 1;            // column 0 belongs to the k = 0 block
+    const int ntile = (RN + 15) / 16;
+    load_a(a, 0);
+    for (int t = 0; t < ntile; t++) {
+        if (KS <= 20) load_a(an, min(t + 1, ntile - 1));
+        iface_d4 acc = iface_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++)
+            if (ks < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
+        if (okc) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int o = t * 16 + kk + 4 * r;
+                if (o < RN) out[(int64_t)o * cwm + j] = acc[r];
+            }
+        }
+        if (KS <= 20) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) a[ks] = an[ks];
+        } else if (t + 1 < ntile) {
+            load_a(a, t + 1);
+        }
     }
 }
 
 // a = y' + Z c for the tile's own unknowns, the rows that depend on them through a boundary condition, and the rows that
-// came back from their owners; writes the patch A rows [cell0, cell0 + nbt).  grid: x = columns / 256, y = tile row.
-__global__ void __launch_bounds__(256)
+// came back from their owners; writes the patch A rows [cell0, cell0 + nbt).  Lane per column (or (Re, Im) pair) walking
+// the tile's rows: the column's 10 returned values are loaded once, Z rows are wave-uniform (scalar loads).
+// grid as k_iface_local.
+template <class T>
+__device__ __forceinline__ void iface_apply_columns(const double *__restrict__ Y, const double *__restrict__ rp, int64_t cwd,
+                                                    double *__restrict__ A, const int *__restrict__ m, const double *__restrict__ gl,
+                                                    const double *__restrict__ gr, const double *Zc, int nbt, int64_t C,
+                                                    int64_t col, bool active) {
+    const int nt = m[0], rb = m[1], nlead = m[2], ntrail = m[3];
+    T *tp = nullptr;
+    T cv[IF_R];
+    if (active) {
+#pragma unroll
+        for (int jx = 0; jx < IF_R; jx++) cv[jx] = ldp(rp + (int64_t)jx * cwd, tp);
+    }
+    extern __shared__ double sz[];                   // [nt][6]
+    for (int e = threadIdx.x; e < nt * IF_E; e += blockDim.x) sz[e] = Zc[e];
+    __syncthreads();
+    if (!active) return;
+    Zc = sz;
+    auto corr = [&](int i, T a) {
+#pragma unroll
+        for (int jx = 0; jx < IF_E; jx++) a = a + Zc[i * IF_E + jx] * cv[jx];
+        return a;
+    };
+    T a0 = zerop(tp), a1 = zerop(tp), am1 = zerop(tp), am2 = zerop(tp);
+    constexpr int U = 8;
+    for (int i0 = 0; i0 < nt; i0 += U) {
+        T yv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) yv[u] = ldp(Y + (int64_t)(rb + min(i0 + u, nt - 1)) * C + col, tp);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int i = i0 + u;
+            if (i < nt) {
+                const T a = corr(i, yv[u]);
+                stp(A + (int64_t)(rb + i) * C + col, a);
+                if (i == 0) a0 = a;
+                if (i == 1) a1 = a;
+                if (i == nt - 1) am1 = a;
+                if (i == nt - 2) am2 = a;
+            }
+        }
+    }
+    for (int q = 0; q < nlead; q++) stp(A + (int64_t)q * C + col, gl[q * 2] * a0 + gl[q * 2 + 1] * a1);
+    for (int q = 0; q < ntrail; q++) stp(A + (int64_t)(nbt - 1 - q) * C + col, gr[q * 2] * am1 + gr[q * 2 + 1] * am2);
+#pragma unroll
+    for (int s = 0; s < IF_X; s++)
+        if (m[4 + s] >= 0) stp(A + (int64_t)m[4 + s] * C + col, cv[IF_E + s]);
+}
+
+__global__ void __launch_bounds__(64)
 k_iface_apply(const double *__restrict__ Y, const double *__restrict__ recv, double *__restrict__ A, const int *__restrict__ owner,
               const int64_t *__restrict__ soff, const int64_t *__restrict__ cw, const int64_t *__restrict__ cs,
               const int *__restrict__ cls, const int *__restrict__ meta, const double *__restrict__ gl,
               const double *__restrict__ gr, const double *__restrict__ Z, int nbt, int Zb, int K2, int64_t C) {
-    const int64_t col = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lr = blockIdx.y;
-    if (col >= C) return;
-    const int g = (int)(col / K2), v = g / Zb, blk = (int)(col - (int64_t)g * K2), d = owner[g];
-    const int c = cls[v * 2 + (blk == 0 ? 0 : 1)];
-    const int *m = meta + c * IF_META;
-    const int nt = m[0], rb = m[1], nlead = m[2], ntrail = m[3];
-    const int64_t cwd = cw[d];
+    const int g = blockIdx.y, v = g / Zb, d = owner[g];
+    const bool k0 = (blockIdx.x == gridDim.x - 1);
+    const int c = cls[v * 2 + (k0 ? 0 : 1)];
+    const int k = 1 + blockIdx.x * 64 + threadIdx.x;
+    const bool act = k0 ? threadIdx.x == 0 : 2 * k + 1 < K2;
+    const int64_t col = (int64_t)g * K2 + (k0 ? 0 : (act ? 2 * k : 2));
     const double *rp = recv + soff[d] + (col - cs[d]);
-    const double *Zc = Z + (int64_t)c * nbt * IF_E;
-    auto unknown = [&](int i) {
-        double a = Y[(int64_t)(rb + i) * C + col];
-#pragma unroll
-        for (int j = 0; j < IF_E; j++) a += Zc[i * IF_E + j] * rp[(int64_t)j * cwd];
-        return a;
-    };
-    double a = 0.0;
-    if (lr >= rb && lr < rb + nt) {
-        a = unknown(lr - rb);
-    } else if (lr < nlead) {
-        a = gl[c * 6 + lr * 2] * unknown(0) + gl[c * 6 + lr * 2 + 1] * unknown(1);
-    } else if (lr >= nbt - ntrail) {
-        const int q = nbt - 1 - lr;
-        a = gr[c * 6 + q * 2] * unknown(nt - 1) + gr[c * 6 + q * 2 + 1] * unknown(nt - 2);
-    } else {
-        for (int s = 0; s < IF_X; s++)
-            if (m[4 + s] == lr) a = rp[(int64_t)(IF_E + s) * cwd];
-    }
-    A[(int64_t)lr * C + col] = a;
+    if (k0) iface_apply_columns<P1>(Y, rp, cw[d], A, meta + c * IF_META, gl + c * 6, gr + c * 6, Z + (int64_t)c * nbt * IF_E, nbt, C, col, act);
+    else iface_apply_columns<P2>(Y, rp, cw[d], A, meta + c * IF_META, gl + c * 6, gr + c * 6, Z + (int64_t)c * nbt * IF_E, nbt, C, col, act);
 }
 
 // ------------------------------------------------------------------------------------------------ host: operators
@@ -316,7 +471,7 @@ static std::vector<xr> mm(const std::vector<xr> &A, const std::vector<xr> &B, in
 
 struct ClassOps {
     int nt = 0, rowbase = 0, nlead = 0, ntrail = 0, xrow[IF_X] = {-1, -1, -1, -1};
-    std::vector<double> Lf, Z, Q;       // [nbt][4], [nbt][6], [RN][RN]
+    std::vector<double> Lf, Z, Q;       // [nbt + 3][4], [nbt][6], Q transposed and padded: [RN inputs][RNp outputs]
 };
 
 // Everything the three kernels need for one boundary-condition class and the tile table; `me` selects whose local factor
@@ -408,7 +563,8 @@ static bool build_class_ops(const SplineClass &sc, int nb, int n, int me, const 
     const std::vector<xr> W = mm(DII, EI, NI, NI, NX), TW = mm(T, W, NI, NI, NX);
     std::vector<xr> Cy = mm(RII, T, NI, NI, NI), Cf = mm(RII, TW, NI, NI, NX);
     const std::vector<xr> Xy = mm(Gx, T, NX, NI, NI), Xf = mm(Gx, TW, NX, NI, NX);
-    out.Q.assign((size_t)RN * RN, 0.0);
+    const int RNp = (RN + 15) / 16 * 16;
+    out.Q.assign((size_t)RN * RNp, 0.0);
     auto row_of = [&](int t, int j) { return t * IF_R + j; };
     for (int t = 0; t < n; t++)
         for (int j = 0; j < IF_R; j++)
@@ -419,7 +575,7 @@ static bool build_class_ops(const SplineClass &sc, int nb, int n, int me, const 
                     else if (j < IF_E) q = EI[(size_t)(t * IF_E + j) * NX + (t2 * IF_X + j2 - IF_E)] - Cf[(size_t)(t * IF_E + j) * NX + (t2 * IF_X + j2 - IF_E)];
                     else if (j2 < IF_E) q = Xy[(size_t)(t * IF_X + j - IF_E) * NI + (t2 * IF_E + j2)];
                     else q = Xf[(size_t)(t * IF_X + j - IF_E) * NX + (t2 * IF_X + j2 - IF_E)];
-                    out.Q[(size_t)row_of(t, j) * RN + row_of(t2, j2)] = (double)q;
+                    out.Q[(size_t)row_of(t2, j2) * RNp + row_of(t, j)] = (double)q;
                 }
     // this tile
     out.nt = u1[me] - u0[me];
@@ -435,7 +591,7 @@ static bool build_class_ops(const SplineClass &sc, int nb, int n, int me, const 
         if (!found) { err = "interface-only solve: unexpected row / unknown correspondence"; return false; }
     }
     if (out.rowbase < 0 || out.rowbase + out.nt > nbt_me) { err = "interface-only solve: unknowns outside the tile's rows"; return false; }
-    out.Lf.assign((size_t)nbt_me * 4, 0.0);
+    out.Lf.assign((size_t)(nbt_me + 3) * 4, 0.0);        // three zero rows behind the last unknown (see the back substitutions)
     out.Z.assign((size_t)nbt_me * IF_E, 0.0);
     for (int i = 0; i < out.nt; i++) {
         for (int q = 0; q < 3; q++) out.Lf[(size_t)i * 4 + q] = (double)Lme[(size_t)i * 4 + q];
@@ -460,8 +616,8 @@ static bool up(sx_handle *h, IfaceState *st, T **p, const std::vector<T> &v) {
 void iface_release(sx_handle *h) {
     IfaceState *st = (IfaceState *)h->iface_state;
     if (!st) return;
-    hipStreamSynchronize(h->stream);
-    for (void *b : st->bufs) hipFree(b);
+    (void)hipStreamSynchronize(h->stream);
+    for (void *b : st->bufs) (void)hipFree(b);
     delete st;
     h->iface_state = nullptr;
 }
@@ -476,15 +632,16 @@ int sx_iface_configure(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0
     clear_error();
     if (!tile_table_ok(h, n, me, cell0, ncells)) return 1;
     if (n < 2) { set_error("interface-only solve needs at least 2 tiles (one tile: sx_spline_transform)"); return 1; }
-    if (n > 16) { set_error("interface-only solve: at most 16 tiles (the reduced system's operator rows live in LDS)"); return 1; }
+    if (n > 16) { set_error("interface-only solve: at most 16 tiles"); return 1; }
     iface_release(h);
     IfaceState *st = new IfaceState();
     h->iface_state = st;
     st->n = n; st->me = me;
     std::string err;
     std::vector<int> meta((size_t)h->ncls * IF_META);
-    const int RN = IF_R * n;
-    std::vector<double> Lf((size_t)h->ncls * h->nbt * 4), Z((size_t)h->ncls * h->nbt * IF_E), Q((size_t)h->ncls * RN * RN);
+    const int RN = IF_R * n, RNp = (RN + 15) / 16 * 16;
+    std::vector<double> Lf((size_t)h->ncls * (h->nbt + 3) * 4), Z((size_t)h->ncls * h->nbt * IF_E), Q((size_t)h->ncls * RN * RNp);
+    int nt_max = 0;
     for (int c = 0; c < h->ncls; c++) {
         ClassOps co;
         if (!build_class_ops(h->classes[c], h->b_rDim, n, me, cell0, ncells, h->nbt, co, err)) {
@@ -495,9 +652,10 @@ int sx_iface_configure(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0
         int *m = &meta[(size_t)c * IF_META];
         m[0] = co.nt; m[1] = co.rowbase; m[2] = co.nlead; m[3] = co.ntrail;
         for (int s = 0; s < IF_X; s++) m[4 + s] = co.xrow[s];
-        std::copy(co.Lf.begin(), co.Lf.end(), Lf.begin() + (size_t)c * h->nbt * 4);
+        nt_max = std::max(nt_max, co.nt);
+        std::copy(co.Lf.begin(), co.Lf.end(), Lf.begin() + (size_t)c * (h->nbt + 3) * 4);
         std::copy(co.Z.begin(), co.Z.end(), Z.begin() + (size_t)c * h->nbt * IF_E);
-        std::copy(co.Q.begin(), co.Q.end(), Q.begin() + (size_t)c * RN * RN);
+        std::copy(co.Q.begin(), co.Q.end(), Q.begin() + (size_t)c * RN * RNp);
     }
     // columns split over the ranks by whole (variable, z-mode) groups, as in the transposed solve
     const int G = h->V * h->Zb;
@@ -512,6 +670,7 @@ int sx_iface_configure(sx_handle *h, int32_t n, int32_t me, const int32_t *cell0
         o += (int64_t)IF_R * cw[d];
     }
     st->colstart = cs;
+    st->nt_max = nt_max;
     st->g0 = (int)(cs[me] / h->K2);
     st->g1 = (int)(cs[me + 1] / h->K2);
     std::vector<int64_t> csn(cs.begin(), cs.begin() + n);
@@ -542,8 +701,11 @@ int sx_iface_local(sx_handle *h, void *dev_send) {
     const int id = timer_id(h, "k_iface_local");
     timer_begin(h, id);
     dim3 g((h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1, h->V * h->Zb);
-    hipLaunchKernelGGL(k_iface_local, g, dim3(64), sizeof(double) * 4 * (h->nbt + 3), h->stream, h->d_Btile, st->d_Y, (double *)dev_send,
-                       st->d_owner, st->d_soff, st->d_cw, st->d_cs, h->d_cls, st->d_meta, h->d_gl, h->d_gr, st->d_Lf, h->nbt, h->Zb, h->K2, h->C);
+#define IFL_ARGS h->d_Btile, st->d_Y, (double *)dev_send, st->d_owner, st->d_soff, st->d_cw, st->d_cs, h->d_cls, st->d_meta, h->d_gl, h->d_gr, \
+                 st->d_Lf, h->nbt, h->Zb, h->K2, h->C
+    if (st->nt_max <= IF_NT_REGS) hipLaunchKernelGGL(k_iface_local<true>, g, dim3(64), sizeof(double) * 4 * (h->nbt + 3), h->stream, IFL_ARGS);
+    else hipLaunchKernelGGL(k_iface_local<false>, g, dim3(64), sizeof(double) * 4 * (h->nbt + 3), h->stream, IFL_ARGS);
+#undef IFL_ARGS
     HIPCHK(hipGetLastError());
     timer_end(h);
     return error_status();
@@ -555,10 +717,14 @@ int sx_iface_reduce(sx_handle *h, const void *dev_recv, void *dev_send) {
     if (!st || !dev_recv || !dev_send) { set_error("sx_iface_reduce: invalid argument / not configured"); return 1; }
     const int id = timer_id(h, "k_iface_reduce");
     timer_begin(h, id);
-    const int ng = st->g1 - st->g0, RN = IF_R * st->n;
+    const int ng = st->g1 - st->g0, RN = IF_R * st->n, RNp = (RN + 15) / 16 * 16;
     if (ng > 0) {
-        hipLaunchKernelGGL(k_iface_reduce, dim3(ng, st->n), dim3(256), sizeof(double) * 2 * IF_R * RN, h->stream, (const double *)dev_recv,
-                           (double *)dev_send, st->d_Q, h->d_cls, st->g0, h->Zb, h->K2, (int64_t)ng * h->K2, RN);
+        const int nchunk = (h->K2 + 63) / 64;        // a block = 4 waves x 16 columns
+#define IFR_ARGS dim3(ng * nchunk + ng), dim3(256), 0, h->stream, (const double *)dev_recv, (double *)dev_send, st->d_Q, h->d_cls, st->g0, ng, nchunk, \
+                 h->Zb, h->K2, (int64_t)ng * h->K2, RN, RNp
+        if (RN <= 80) hipLaunchKernelGGL(k_iface_reduce<20>, IFR_ARGS);
+        else hipLaunchKernelGGL(k_iface_reduce<40>, IFR_ARGS);
+#undef IFR_ARGS
         HIPCHK(hipGetLastError());
     }
     timer_end(h);
@@ -571,7 +737,7 @@ int sx_iface_apply(sx_handle *h, const void *dev_recv) {
     if (!st || !dev_recv) { set_error("sx_iface_apply: invalid argument / not configured"); return 1; }
     const int id = timer_id(h, "k_iface_apply");
     timer_begin(h, id);
-    hipLaunchKernelGGL(k_iface_apply, dim3((unsigned)((h->C + 255) / 256), h->nbt), dim3(256), 0, h->stream, st->d_Y, (const double *)dev_recv,
+    hipLaunchKernelGGL(k_iface_apply, dim3((h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1, h->V * h->Zb), dim3(64), sizeof(double) * IF_E * h->nbt, h->stream, st->d_Y, (const double *)dev_recv,
                        h->d_A + (int64_t)h->cell0 * h->C, st->d_owner, st->d_soff, st->d_cw, st->d_cs, h->d_cls, st->d_meta, h->d_gl, h->d_gr,
                        st->d_Z, h->nbt, h->Zb, h->K2, h->C);
     HIPCHK(hipGetLastError());

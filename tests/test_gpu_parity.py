@@ -146,13 +146,14 @@ def test_tiles_on_one_gpu_match_single_patch_oracle(maker, kw, ntiles, exchange,
 @pytest.mark.parametrize("maker,kw,ntiles", [(cases.rlz_hrbl, {"num_cells": 24, "zDim": 32, "ring_L": 16}, 3),
                                              (cases.rlz_hrbl, {"num_cells": 20, "zDim": 10}, 2),            # native ragged rings
                                              (cases.kat_r, {}, 2), (cases.kat_r, {}, 3), (cases.kat_r, {}, 8),   # PERIODIC: wrap-around rows
-                                             (cases.rl_slab, {"num_cells": 20}, 2), (cases.rl_slab, {"num_cells": 31}, 4),
+                                             (cases.rl_slab, {"num_cells": 20}, 2), (cases.rl_slab, {"num_cells": 30}, 3), (cases.rl_slab, {"num_cells": 31, "ring_L": 16}, 4),
+                                             (cases.rl_slab, {"num_cells": 80, "ring_L": 16}, 2),            # 40 unknowns per tile: memory-resident local solve
                                              (cases.rz_semiimplicit, {"num_cells": 21}, 3),
                                              (cases.r_bcs, {"bcl": "R0", "bcr": "R0", "num_cells": 40}, 4),
                                              (cases.r_bcs, {"bcl": "R1T0", "bcr": "R1T1", "num_cells": 40}, 4),
                                              (cases.r_bcs, {"bcl": "R1T2", "bcr": "R2T10", "num_cells": 40}, 3),
                                              (cases.r_bcs, {"bcl": "R2T20", "bcr": "R3", "num_cells": 40}, 4),
-                                             (cases.r_bcs, {"bcl": "R3", "bcr": "R1T0", "num_cells": 64}, 8)])
+                                             (cases.r_bcs, {"bcl": "R3", "bcr": "R1T0", "num_cells": 72}, 8)])
 @pytest.mark.parametrize("impl", ["torch", "lib"])
 def test_interface_only_solve_on_tiles_matches_single_patch_oracle(maker, kw, ntiles, impl):
     """The interface-only ("partitioned") patch solve - every tile solves its own rows, 10 rows per tile and column go
