@@ -10,9 +10,10 @@ One "step" is one pass of model_loop's body (src/semiimplicit.jl:268-297): tileT
 (Oneway_ShallowWater_HeightResolvedBL) -> explicit_timestep -> spectralTransform! -> halo/sum -> splineTransform!.
 Workload (SURVEY.md 8(d) "perf shape"): 171 radial cells -> 513 rings x 256 azimuthal points x 64 Chebyshev levels,
 6 variables, 7 derivative slots, fp64, synthetic vortex initial condition resident in HBM before the timed region.
-For N > 1 the 171 cells are split into N radial tiles, one per GPU (strong scaling); the patch-level B -> A solve is
-transposed across the GPUs with two RCCL all-to-alls per step (--exchange gather selects the reference's protocol:
-halo rank -> rank+1, all-gather of owned rows, redundant patch solve).
+For N > 1 the 171 cells are split into N radial tiles, one per GPU (strong scaling); the patch-level B -> A solve runs in its
+interface-only form (every rank solves its own rows, two RCCL all-to-alls of 10 rows per tile around a small reduced system;
+--exchange a2a: the transposed solve, --exchange gather: the reference's protocol - halo rank -> rank+1, all-gather of owned
+rows, redundant patch solve).
 
 Prints ONE JSON line on rank 0 with the driver's contract plus "roofline" (dominant kernel, live hipEvent timing) and
 "cpu_baseline" (the C oracle "port" on a bounded radial sample of the same workload, rank 0, N = 1 only).
@@ -139,8 +140,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="rlz_513x256x64", choices=sorted(WORKLOADS))
-    ap.add_argument("--exchange", default="a2a", choices=["a2a", "gather"],
-                    help="multi-GPU patch solve: transposed all-to-all (default) or the reference's halo + gather protocol")
+    ap.add_argument("--exchange", default="iface", choices=["iface", "a2a", "gather"],
+                    help="multi-GPU patch solve: interface-only solve (default: tile-local solves, two all-to-alls of 10 rows per tile; "
+                         "falls back to a2a when a tile has fewer than 9 cells), transposed all-to-all, or the reference's halo + gather protocol")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --one-device rehearses the multi-rank path on a single GPU (not a performance mode)")
     ap.add_argument("--one-device", action="store_true", help="every rank uses cuda:0 (rehearsal only)")
@@ -191,6 +193,11 @@ def main():
     mp = S.ModelParameters(ts=TS_OF.get(args.workload, TS), equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
                            physical_params=dict(PAR))
     impl = args.exchange_impl if (world > 1 and args.backend == "nccl") else "torch"
+    if args.exchange == "iface" and world > 1:
+        # the interface-only solve needs 6 free spline coefficients per tile (up to 3 more cells where a rank-3 boundary condition
+        # takes rows away): decided from the tile table, i.e. identically on every rank
+        if min(S.PatchLayout(gp, world, split=args.tile_split).ncells) < 9:
+            args.exchange = "a2a"
     dev = torch.device("cuda", local_rank)
     selfcheck = None
 

@@ -32,7 +32,7 @@ def _worker(rank, world, port, exchange, q, case_kw=None):
         import scythe_jl_amd as S
         from tests import cases
         torch.cuda.set_device(0)
-        case = cases.rlz_hrbl(**(case_kw or dict(num_cells=8, zDim=12, ring_L=32)))
+        case = cases.rlz_hrbl(**(case_kw or dict(num_cells=18 if exchange == "iface" else 8, zDim=12, ring_L=32)))
         gp, mp_ = cases.hip_params(case)
         run = S.ModelRun(mp_, num_tiles=world, rank=rank, device=torch.device("cuda", 0), use_dist=True, exchange=exchange)
         tile = run.tiles[0]
@@ -53,7 +53,7 @@ def _worker(rank, world, port, exchange, q, case_kw=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["a2a", "gather"])
+@pytest.mark.parametrize("exchange", ["a2a", "gather", "iface"])
 def test_two_ranks_one_gpu(exchange):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -108,7 +108,7 @@ def test_bench_cli_two_ranks_on_one_device():
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in d, key
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["nan"] is False
-    assert d["config"]["exchange"] == "a2a" and "cpu_baseline" not in d
+    assert d["config"]["exchange"] == "iface" and "cpu_baseline" not in d      # rlz_small: 24 cells, 12 per rank
 
 
 @pytest.mark.gpu
@@ -131,7 +131,7 @@ def test_bench_cli_two_ranks_self_spawned():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("exchange", ["a2a", "gather"])
+@pytest.mark.parametrize("exchange", ["a2a", "gather", "iface"])
 @pytest.mark.parametrize("maker,kw", [(cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}), (cases.rl_slab, {"num_cells": 9}),
                                        (cases.rz_semiimplicit, {"num_cells": 9})])
 def test_in_library_rccl_exchange_world_size_one(maker, kw, exchange):
@@ -171,7 +171,7 @@ def test_bench_cli_two_ranks_rccl():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    for exchange in ("a2a", "gather"):
+    for exchange in ("iface", "a2a", "gather"):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                "--workload", "rlz_small", "--exchange", exchange]
