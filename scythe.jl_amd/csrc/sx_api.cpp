@@ -532,8 +532,17 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
                         it.push_back({(int64_t)h->hL[r] * h->hL[r] * planes, r, v});
                     }
                 std::stable_sort(it.begin(), it.end(), [](const auto &a, const auto &b) { return a[0] > b[0]; });
+                // rings whose coefficient sets do not fit the LDS in one piece (kmax > 319) go first and take the chunked
+                // kernels (sx_dft.hip); the rest keeps the single-pass kernels, sized for ITS largest ring
+                std::stable_partition(it.begin(), it.end(), [&](const auto &e) { return h->hkmax[e[1]] > DFT_KMAX_SINGLE; });
                 std::vector<int> flat;
-                for (const auto &e : it) { flat.push_back((int)e[1]); flat.push_back((int)e[2]); }
+                int nbig = 0;
+                for (const auto &e : it) {
+                    flat.push_back((int)e[1]); flat.push_back((int)e[2]);
+                    if (h->hkmax[e[1]] > DFT_KMAX_SINGLE) nbig++;
+                    else { h->dft_lcap_small = std::max(h->dft_lcap_small, h->hL[e[1]]); h->dft_kcap_small = std::max(h->dft_kcap_small, h->hkmax[e[1]]); }
+                }
+                h->n_dft_big[which] = nbig;
                 h->n_dft_items[which] = (int)it.size();
                 if (!upload(h, &h->d_dft_items[which], flat)) FAIL();
             }

@@ -43,6 +43,7 @@ __device__ long long *g_dft_dbg = nullptr;
 #define DFT_NOW() 0ll
 #endif
 
+constexpr int DFT_LMAX = 5120;   // longest ring the LDS-resident twiddle table allows (native patches up to 426 cells, kmax 1279)
 constexpr int DZC = 16;       // levels per workgroup = MFMA N
 constexpr int CST = 17;       // row stride (doubles) of the LDS tiles: 4 consecutive rows land in different banks
 
@@ -248,6 +249,130 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
 #endif
 }
 
+
+// The same transform for rings whose coefficient sets do not fit the LDS next to the twiddle table (kmax > 319, i.e. native
+// patches of more than 106 cells: a 171-cell patch has rings of 2,052 points with kmax 512).  Loop order inverted: a
+// workgroup owns ONE group of 8 row tiles (128 points of the quarter ring, blockIdx.z), its accumulators stay in registers
+// while the wavenumbers pass through the LDS in chunks of KCH; every coefficient set is staged once per row-tile group.
+// Simpler staging than the kernel above (no request-ahead across sets): these rings are few and large.
+constexpr int KCH = 256;      // wavenumbers per staged chunk (a multiple of 8: a K step covers 8 wavenumbers of one parity)
+
+template <class ST>
+__global__ void __launch_bounds__(512)
+k_rl_inverse_dft_big(const double *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi, const int *__restrict__ Lr,
+                     const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
+                     const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
+                     int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow, int s_u, int s_r, int s_rr, int s_l, int s_ll,
+                     int s_z, int s_zz, const int *__restrict__ slotmask, const int *__restrict__ items, int lcap) {
+    extern __shared__ double sm[];
+    const int ring = items[2 * blockIdx.y], v = items[2 * blockIdx.y + 1], z0 = blockIdx.x * DZC;
+    const int mask = slotmask[v];
+    const int zc = min(DZC, nz - z0);
+    const int L = Lr[ring], km = kmaxr[ring], Lh = L / 2, Lq = L / 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    const int mt = blockIdx.z * nw + wave;                       // this wave's row tile of the quarter ring
+    if ((int)blockIdx.z * nw * 16 > Lq) return;                  // no row tile group here (uniform for the workgroup)
+    const bool rows = mt * 16 <= Lq;
+    double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]
+    double *Cc = sm + 2 * (size_t)lcap;                         // [KCH][CST]
+    double *Cs = Cc + (size_t)KCH * CST;
+    const int j0 = ring / MUBAR;
+    const double2 *phr = ph + phoff[ring];
+    const int64_t p0 = pstart[ring];
+    for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
+    const int i = lane & 15, kk = lane >> 4;
+    const int lrow = min(mt * 16 + i, Lq);
+    const int sm8 = (int)(((int64_t)8 * lrow) % L);
+    for (int q = 0; q < 5; q++) {
+        const int sz = q < 3 ? 0 : q - 2, d = q < 3 ? q : 0;
+        if (sz >= nsz) break;
+        const int slot0 = (q == 0) ? s_u : (q == 1) ? s_r : (q == 2) ? s_rr : (q == 3) ? s_z : s_zz;
+        const bool need0 = (mask >> slot0) & 1;
+        const bool needl = (q == 0) && ((mask >> s_l) & 1), needll = (q == 0) && ((mask >> s_ll) & 1);
+        if (!need0 && !needl && !needll) continue;
+        const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
+        const double f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
+        dft_d4 z4 = {0.0, 0.0, 0.0, 0.0};
+        dft_d4 pu[2] = {z4, z4}, qu[2] = {z4, z4}, pl[2] = {z4, z4}, ql[2] = {z4, z4}, pll[2] = {z4, z4}, qll[2] = {z4, z4};
+        for (int kc0 = 0; kc0 <= km; kc0 += KCH) {
+            __syncthreads();                                    // the previous chunk has been consumed (and twl is complete)
+            // stage wavenumbers kc0 .. kc0 + KCH - 1: thread -> (level, wavenumber), 4 radial rows as 16-byte (Re, Im) pairs
+            for (int e = tid; e < KCH * DZC; e += blockDim.x) {
+                const int zz = (e >> 5) & (DZC - 1), kl = (e & 31) + 32 * (e >> 9), k = kc0 + kl;     // 32 consecutive wavenumbers of a level per half wave
+                double cr = 0.0, ci = 0.0;
+                if (zz < zc && k <= km) {
+                    const double *a = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + zz)) * K2 + 2 * k;
+                    const double2 r0 = *reinterpret_cast<const double2 *>(a), r1 = *reinterpret_cast<const double2 *>(a + azrow),
+                                  r2 = *reinterpret_cast<const double2 *>(a + 2 * azrow), r3 = *reinterpret_cast<const double2 *>(a + 3 * azrow);
+                    cr = f0 * r0.x + f1 * r1.x + f2 * r2.x + f3 * r3.x;
+                    if (k > 0) {
+                        ci = f0 * r0.y + f1 * r1.y + f2 * r2.y + f3 * r3.y;
+                        const double2 w = phr[k];               // e^{+i k off}
+                        const double tr = cr * w.x - ci * w.y;
+                        ci = 2.0 * (cr * w.y + ci * w.x);
+                        cr = 2.0 * tr;
+                    }
+                }
+                Cc[kl * CST + zz] = cr;
+                Cs[kl * CST + zz] = ci;
+            }
+            __syncthreads();
+            if (!rows) continue;
+            const int kend = min(km, kc0 + KCH - 1);
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                // this lane's wavenumber k = kc0 + 8 js + 2 kk + par; angle index (k l) mod L advances by 8 l per step
+                int k = kc0 + 2 * kk + par;
+                int m = (int)(((int64_t)k * lrow) % L);
+                double kd = (double)k;
+                for (int js = 0; kc0 + 8 * js + par <= kend; js++, k += 8) {
+                    const bool kin = k <= kend;
+                    const double2 t0 = twl[m];
+                    const double bc = kin ? Cc[(k - kc0) * CST + i] : 0.0, bs = kin ? Cs[(k - kc0) * CST + i] : 0.0;
+                    if (need0) {
+                        pu[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, pu[par], 0, 0, 0);
+                        qu[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, qu[par], 0, 0, 0);
+                    }
+                    if (needl) {
+                        pl[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, -kd * bs, pl[par], 0, 0, 0);
+                        ql[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, kd * bc, ql[par], 0, 0, 0);
+                    }
+                    if (needll) {
+                        const double k2 = -(kd * kd);
+                        pll[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, k2 * bc, pll[par], 0, 0, 0);
+                        qll[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, k2 * bs, qll[par], 0, 0, 0);
+                    }
+                    kd += 8.0;
+                    m += sm8;
+                    if (m >= L) m -= L;
+                }
+            }
+        }
+        if (!rows || i >= zc) continue;
+        auto put = [&](int slot, int64_t pt, double val) {
+            if (slot == 0) phys.val[(int64_t)v * N + pt] = val;
+            else phys.der[((int64_t)(slot - 1) * V + v) * N + pt] = (ST)val;
+        };
+        auto put4 = [&](int slot, int lo, double Pe, double Po, double Qe, double Qo) {
+            const double Ps = Pe + Po, Pd = Pe - Po, Qs = Qe + Qo, Qd = Qe - Qo;
+            put(slot, (p0 + lo) * nz + z0 + i, Ps - Qs);
+            if (lo > 0) put(slot, (p0 + (L - lo)) * nz + z0 + i, Ps + Qs);
+            if (lo < Lq) {
+                put(slot, (p0 + (Lh - lo)) * nz + z0 + i, Pd + Qd);
+                if (lo > 0) put(slot, (p0 + (Lh + lo)) * nz + z0 + i, Pd - Qd);
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int lo = mt * 16 + kk + 4 * r;
+            if (lo > Lq) continue;
+            if (need0) put4(slot0, lo, pu[0][r], pu[1][r], qu[0][r], qu[1][r]);
+            if (needl) put4(s_l, lo, pl[0][r], pl[1][r], ql[0][r], ql[1][r]);
+            if (needll) put4(s_ll, lo, pll[0][r], pll[1][r], qll[0][r], qll[1][r]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ inverse, RL grids
 // Without a vertical dimension the MFMA columns are the requested (variable, derivative plane) pairs of the ring (19 for the
 // shallow-water slab sets): all coefficient sets - value, d/dr, d2/dr2 by radial evaluation, d/dlambda, d2/dlambda2 by
@@ -265,7 +390,7 @@ __global__ void __launch_bounds__(512)
 k_rl_inverse_dft_planes(const double *__restrict__ A, Planes<ST> phys, const double *__restrict__ phi, const int *__restrict__ Lr,
                         const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
                         const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
-                        int K2, int nrings, int64_t N, int64_t arow, PlaneGroups pgs, int ring0, int lcap, int kcap4) {
+                        int K2, int nrings, int64_t N, int64_t arow, PlaneGroups pgs, int ring0, int lcap, int kch4) {
     extern __shared__ double sm[];
     const PlaneCols &pc = pgs.g[blockIdx.z];
     // one ring has too little work per plane to fill the chip with a workgroup per ring (300 rings at config 2): the ring's
@@ -276,53 +401,57 @@ k_rl_inverse_dft_planes(const double *__restrict__ A, Planes<ST> phys, const dou
     if (part * (int)(blockDim.x >> 6) * 16 > Lh) return;        // nothing for this part (uniform for the workgroup)
     const int K4 = (km + 1 + 3) & ~3;
     double2 *twl = reinterpret_cast<double2 *>(sm);
-    double *Cc = sm + 2 * (size_t)lcap;                         // [K4][CSTP]
-    double *Cs = Cc + (size_t)kcap4 * CSTP;
+    double *Cc = sm + 2 * (size_t)lcap;                         // [kch4][CSTP]: wavenumbers pass through in chunks of kch4
+    double *Cs = Cc + (size_t)kch4 * CSTP;                      //   (one chunk for kmax <= 319; longer rings keep their accumulators across chunks)
     const int j0 = ring / MUBAR;
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
     for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
-    for (int e = tid; e < K4 * CSTP; e += blockDim.x) { Cc[e] = 0.0; Cs[e] = 0.0; }
-    __syncthreads();
     const double *pf = phi + (int64_t)ring * 4;
-    for (int e = tid; e < V * (km + 1); e += blockDim.x) {
-        const int k = e % (km + 1), v = e / (km + 1);
-        const double *a = A + (int64_t)j0 * arow + (int64_t)v * K2 + 2 * k;
-        double cr[3], ci[3];
+    const int i = lane & 15, kk = lane >> 4;
+    // ONE pair of row tiles per wave (the launcher gives the ring ceil(tiles / 16) workgroups of 8 waves)
+    const int mt = part * nw + wave, mtb = mt + nw * nparts;
+    const bool one = mt * 16 <= Lh, two = mtb * 16 <= Lh;
+    RowPair rp;
+    rp.init(min(mt * 16 + i, Lh), min(mtb * 16 + i, Lh), kk, L);
+    dft_d4 p0a = {0.0, 0.0, 0.0, 0.0}, q0a = p0a, p1a = p0a, q1a = p0a;
+    for (int kc0 = 0; kc0 < K4; kc0 += kch4) {
+        const int nkc = min(kch4, K4 - kc0), kn = min(km + 1, kc0 + nkc) - kc0;      // rows of this chunk, of which wavenumbers <= km
+        __syncthreads();                                        // the previous chunk has been consumed (and twl is complete)
+        for (int e = tid; e < nkc * CSTP; e += blockDim.x) { Cc[e] = 0.0; Cs[e] = 0.0; }
+        __syncthreads();
+        for (int e = tid; e < V * kn; e += blockDim.x) {
+            const int kl = e % kn, k = kc0 + kl, v = e / kn;
+            const double *a = A + (int64_t)j0 * arow + (int64_t)v * K2 + 2 * k;
+            double cr[3], ci[3];
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const double *f = pf + (int64_t)d * nrings * 4;
-            cr[d] = f[0] * a[0] + f[1] * a[arow] + f[2] * a[2 * arow] + f[3] * a[3 * arow];
-            ci[d] = (k == 0) ? 0.0 : f[0] * a[1] + f[1] * a[arow + 1] + f[2] * a[2 * arow + 1] + f[3] * a[3 * arow + 1];
-            if (k > 0) {
-                const double2 w = phr[k];
-                const double tr = cr[d] * w.x - ci[d] * w.y;
-                ci[d] = 2.0 * (cr[d] * w.y + ci[d] * w.x);
-                cr[d] = 2.0 * tr;
+            for (int d = 0; d < 3; d++) {
+                const double *f = pf + (int64_t)d * nrings * 4;
+                cr[d] = f[0] * a[0] + f[1] * a[arow] + f[2] * a[2 * arow] + f[3] * a[3 * arow];
+                ci[d] = (k == 0) ? 0.0 : f[0] * a[1] + f[1] * a[arow + 1] + f[2] * a[2 * arow + 1] + f[3] * a[3 * arow + 1];
+                if (k > 0) {
+                    const double2 w = phr[k];
+                    const double tr = cr[d] * w.x - ci[d] * w.y;
+                    ci[d] = 2.0 * (cr[d] * w.y + ci[d] * w.x);
+                    cr[d] = 2.0 * tr;
+                }
+            }
+#pragma unroll
+            for (int kind = 0; kind < 5; kind++) {
+                const int c = pc.colof[v][kind];
+                if (c < 0) continue;
+                double xr, xi;
+                if (kind < 3) { xr = cr[kind]; xi = ci[kind]; }
+                else if (kind == 3) { xr = -(double)k * ci[0]; xi = (double)k * cr[0]; }
+                else { xr = -((double)k * k) * cr[0]; xi = -((double)k * k) * ci[0]; }
+                Cc[kl * CSTP + c] = xr;
+                Cs[kl * CSTP + c] = xi;
             }
         }
-#pragma unroll
-        for (int kind = 0; kind < 5; kind++) {
-            const int c = pc.colof[v][kind];
-            if (c < 0) continue;
-            double xr, xi;
-            if (kind < 3) { xr = cr[kind]; xi = ci[kind]; }
-            else if (kind == 3) { xr = -(double)k * ci[0]; xi = (double)k * cr[0]; }
-            else { xr = -((double)k * k) * cr[0]; xi = -((double)k * k) * ci[0]; }
-            Cc[k * CSTP + c] = xr;
-            Cs[k * CSTP + c] = xi;
-        }
-    }
-    __syncthreads();
-    const int i = lane & 15, kk = lane >> 4;
-    for (int mt = part * nw + wave; mt * 16 <= Lh; mt += 2 * nw * nparts) {
-        const int mtb = mt + nw * nparts;
-        const bool two = mtb * 16 <= Lh;
-        RowPair rp;
-        rp.init(min(mt * 16 + i, Lh), min(mtb * 16 + i, Lh), kk, L);
-        dft_d4 p0a = {0.0, 0.0, 0.0, 0.0}, q0a = p0a, p1a = p0a, q1a = p0a;
-        for (int js = 0; js < K4 / 4; js++) {
+        __syncthreads();
+        if (!one) continue;
+        for (int js = 0; js < nkc / 4; js++) {
             const double2 t0 = twl[rp.m0], t1 = twl[rp.m1];
             const double bc = Cc[(4 * js + kk) * CSTP + i], bs = Cs[(4 * js + kk) * CSTP + i];
             p0a = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, p0a, 0, 0, 0);
@@ -333,7 +462,8 @@ k_rl_inverse_dft_planes(const double *__restrict__ A, Planes<ST> phys, const dou
             }
             rp.step(L);
         }
-        if (i >= pc.n) continue;
+    }
+    if (one && i < pc.n) {
         const int vv = pc.v[i], sl = pc.slot[i];
         auto put = [&](int64_t pt, double val) {
             if (sl == 0) phys.val[(int64_t)vv * N + pt] = val;
@@ -474,9 +604,12 @@ k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, cons
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
     const int n = lane & 15, kk = lane >> 4;
-    const int par = wave & 1, tq = wave >> 1;                       // this wave's parity and first tile
+    // rings with more than 4 x NTW tiles per parity (kmax > 383) spread their tiles over gridDim.z workgroups, each folding
+    // the ring for itself; blockIdx.z = 0 is all there is for the others
+    const int par = wave & 1, tq = (wave >> 1) + 4 * NTW * (int)blockIdx.z;     // this wave's parity and first tile
     const int nk = km >= par ? (km - par) / 2 + 1 : 0;              // wavenumbers of this parity
     const int ntile = (nk + 15) / 16;
+    if (4 * NTW * (int)blockIdx.z * 16 >= (km / 2 + 1)) return;     // no tile of either parity in this part (uniform for the workgroup)
     dft_d4 ac[NTW], as[NTW];
     int kq[NTW], fourk[NTW];
 #pragma unroll
@@ -557,7 +690,8 @@ k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, cons
 static bool dft_planes(const sx_handle *h) { return !h->has_z; }
 
 bool dft_mfma_ok(const sx_handle *h) {
-    if (!h->has_l || fft_path_ok(h) || h->kmax_max > 319) return false;
+    if (!h->has_l || fft_path_ok(h)) return false;
+    if (h->L_max > DFT_LMAX) return false;      // twiddle table (16 bytes per ring point) + staged chunks must fit 160 KB of LDS
     if (dft_planes(h) ? (h->V > 8 || h->D > 5) : h->nz < 8) return false;
     static const bool off = getenv("SX_DFT_MFMA") && atoi(getenv("SX_DFT_MFMA")) == 0;       // scalar kernels instead (debugging)
     if (off) return false;
@@ -603,9 +737,9 @@ static void launch_rl_inverse_dft_planes(sx_handle *h, bool full) {
     const double *a = h->d_A + (int64_t)h->cell0 * h->C;
     // two launch classes only: each launch is as long as its largest ring's workgroup, so more classes mostly add tails
     for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int kcap) {
-        const int kcap4 = (kcap + 1 + 3) & ~3;
+        const int kcap4 = std::min((kcap + 1 + 3) & ~3, KCH);                               // wavenumbers staged per chunk
         const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)2 * kcap4 * CSTP);
-        const int nsplit = std::min(8, std::max(1, ((lcap / 2 + 16) / 16 + 15) / 16));      // 8 waves x 2 row tiles of the half ring per pass
+        const int nsplit = std::max(1, ((lcap / 2 + 16) / 16 + 15) / 16);                   // 8 waves x ONE pair of row tiles of the half ring each
 #define DFT_INVP(ST)                                                                                                                 \
         {                                                                                                                            \
             auto kern = k_rl_inverse_dft_planes<ST>;                                                                                 \
@@ -658,9 +792,27 @@ void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
         // ONE launch over the (ring, variable) work list, most expensive first (four launches by ring size, rings in
         // increasing order: 1.63 ms; one launch, largest first: 1.41 ms - the large rings no longer form the tail)
         const int which = d_mask == h->d_mask_full ? 1 : 0;
-        const int lcap = h->L_max, kcap4 = (h->kmax_max + 1 + 3) & ~3;
+        const int nbig = h->n_dft_big[which];
+        if (nbig > 0) {      // rings with kmax > 319 (listed first): wavenumbers in chunks, one group of 8 row tiles per workgroup
+            const int lcapb = h->L_max;
+            const size_t ldsb = sizeof(double) * (2 * (size_t)lcapb + (size_t)2 * KCH * CST);
+            dim3 gb((h->nz + DZC - 1) / DZC, nbig, (lcapb / 4 / 16 + 1 + 7) / 8);
+#define DFT_INVB(ST)                                                                                                                 \
+            {                                                                                                                        \
+                auto kern = k_rl_inverse_dft_big<ST>;                                                                                \
+                HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb)); \
+                hipLaunchKernelGGL(kern, gb, dim3(512), ldsb, h->stream, az, planes_of<ST>(h->d_phys, h->V, h->N), h->d_phi, h->d_L, \
+                                   h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2,     \
+                                   h->nrings, h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5],   \
+                                   h->slot[6], d_mask, h->d_dft_items[which], lcapb);                                                \
+            }
+            if (h->f32) DFT_INVB(float) else DFT_INVB(double)
+#undef DFT_INVB
+            HIPCHK3(hipGetLastError());
+        }
+        const int lcap = h->dft_lcap_small, kcap4 = (h->dft_kcap_small + 1 + 3) & ~3;
         const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)2 * kcap4 * CST);
-        dim3 g((h->nz + DZC - 1) / DZC, h->n_dft_items[which], 1);
+        dim3 g((h->nz + DZC - 1) / DZC, h->n_dft_items[which] - nbig, 1);
         if (g.y == 0) { timer_end(h); return; }
 #define DFT_INV(ST)                                                                                                                  \
         {                                                                                                                            \
@@ -669,7 +821,7 @@ void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
             hipLaunchKernelGGL(kern, g, dim3(512), lds, h->stream, az, planes_of<ST>(h->d_phys, h->V, h->N), h->d_phi, h->d_L,       \
                                h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2,         \
                                h->nrings, h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5],       \
-                               h->slot[6], d_mask, h->d_dft_items[which], lcap, kcap4);                                              \
+                               h->slot[6], d_mask, h->d_dft_items[which] + 2 * nbig, lcap, kcap4);                                   \
         }
         if (h->f32) DFT_INV(float) else DFT_INV(double)
 #undef DFT_INV
@@ -685,13 +837,21 @@ void launch_fl_forward_dft(sx_handle *h) {
     static const bool half = getenv("SX_DFT_HALF") && atoi(getenv("SX_DFT_HALF")) != 0;      // A/B: the half-ring kernel
     if (!planes && !half) {          // quarter-wave form; 4 waves x NTW tiles x 16 = 192 wavenumbers per parity >= (kmax <= 319) / 2 + 1
         // ONE launch over the work list (four launches by ring size, each with its own tail: 0.32 -> 0.29 ms)
-        const int lcap = h->L_max;
-        const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * LCQ * CST);
-        dim3 g((h->nz + DZC - 1) / DZC, h->n_dft_items[2], 1);
-        HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fl_forward_dft_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_fl_forward_dft_q, g, dim3(512), lds, h->stream, h->d_np1, h->d_Fl, h->d_L, h->d_kmax, h->d_pstart,
-                           h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N, h->d_dft_items[2], lcap);
-        HIPCHK3(hipGetLastError());
+        // rings with kmax > 319 (listed first) in their own launch: the wavenumber tiles of a ring spread over gridDim.z
+        // workgroups (12 tiles of 16 wavenumbers per parity each); the others as before, sized for their largest ring
+        const int nbig = h->n_dft_big[2];
+        for (int part = 0; part < 2; part++) {
+            const int n = part == 0 ? nbig : h->n_dft_items[2] - nbig;
+            if (n == 0) continue;
+            const int lcap = part == 0 ? h->L_max : h->dft_lcap_small;
+            const int kparts = part == 0 ? ((h->kmax_max / 2 + 1 + 15) / 16 + 4 * NTW - 1) / (4 * NTW) : 1;
+            const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * LCQ * CST);
+            dim3 g((h->nz + DZC - 1) / DZC, n, kparts);
+            HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fl_forward_dft_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(k_fl_forward_dft_q, g, dim3(512), lds, h->stream, h->d_np1, h->d_Fl, h->d_L, h->d_kmax, h->d_pstart,
+                               h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N, h->d_dft_items[2] + (part == 0 ? 0 : 2 * nbig), lcap);
+            HIPCHK3(hipGetLastError());
+        }
         timer_end(h);
         return;
     }

@@ -9,6 +9,7 @@
 
 namespace sx {
 
+constexpr int DFT_KMAX_SINGLE = 319;   // largest kmax whose coefficient sets fit the LDS beside the twiddle table (sx_dft.hip)
 constexpr int MUBAR = 3;   // CubicBSpline.mubar: mish points per cell (src/spectralGrid.jl:24)
 
 // ---- host-side operator construction (sx_setup.cpp) ---------------------------------------------------------------
@@ -119,6 +120,8 @@ struct sx_handle {
     // equation-set slot mask, [1] inverse with every slot, [2] forward
     int *d_dft_items[3] = {nullptr, nullptr, nullptr};
     int n_dft_items[3] = {0, 0, 0};
+    int n_dft_big[3] = {0, 0, 0};            // of which (listed first) rings with kmax > DFT_KMAX_SINGLE: chunked kernels
+    int dft_lcap_small = 0, dft_kcap_small = 0;   // largest ring length / kmax among the other rings
     int sbw_mfma = 1;       // k_sbw_mfma (matrix-core vertical contraction, operator in registers) for zDim 64 / 32 (SX_SBW_MFMA=0: k_sbw)
     int sbw_prefetch = 0;   // k_sbw requests the next cell's ring spectra before contracting the current node (SX_SBW_PF=0: off)
     int wide = 1;    // 16-byte-per-lane loads / stores in the equation-set kernels (SX_WIDE=0: the 8-byte forms, A/B timing)

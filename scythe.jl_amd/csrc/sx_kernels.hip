@@ -1772,6 +1772,11 @@ void launch_rl_inverse(sx_handle *h, bool full) {
     timer_begin(h, id);
     const int cstride = (h->kmax_max + 1) | 1;
     const size_t lds = sizeof(double) * 2 * ZC * cstride;
+    if (lds > 64 * 1024) {
+        set_error("azimuthal inverse transform: rings with " + std::to_string(h->kmax_max) + " wavenumbers are outside every transform path (power-of-two ring tables up to 512 points, ring lengths that are multiples of 4 up to 5120 points, otherwise kmax <= 255)");
+        timer_end(h);
+        return;
+    }
     const double *az = h->has_z ? h->d_Az : h->d_A + (int64_t)h->cell0 * h->C;
     const int64_t azrow = h->has_z ? (int64_t)h->V * 3 * h->nz * h->K2 : h->C;
     dim3 g((h->nz + ZC - 1) / ZC, h->V, h->nrings);
@@ -1952,8 +1957,8 @@ void launch_fl_forward(sx_handle *h) {
     timer_begin(h, id);
     const int xstride = h->L_max | 1;
     const size_t lds = sizeof(double) * ZC * xstride;
-    if (lds > 64 * 1024) {       // the scalar kernel stages a whole ring; longer native rings need the matrix-core DFT (kmax <= 319)
-        set_error("azimuthal forward transform: rings of " + std::to_string(h->L_max) + " points are outside every transform path (uniform power-of-two tables up to 512, native rings with kmax <= 319, scalar up to 511 points)");
+    if (lds > 64 * 1024) {       // the scalar kernel stages a whole ring; longer rings need the matrix-core DFT (lengths that are multiples of 4)
+        set_error("azimuthal forward transform: rings of " + std::to_string(h->L_max) + " points are outside every transform path (power-of-two ring tables up to 512 points, ring lengths that are multiples of 4 up to 5120 points, any length up to 511 points)");
         return;
     }
     dim3 g((h->nz + ZC - 1) / ZC, h->V, h->nrings);

@@ -152,6 +152,34 @@ def test_config4_native_equivalent_full_size_against_the_c_oracle():
     _check(hip, orc, [0, 1, 127, 128, 253, 254], "config 4, native-equivalent shape (255 ragged rings x 64 levels, kmax 255), 2 steps")
 
 
+def test_native_rings_of_a_171_cell_patch_beyond_kmax_319():
+    """The "512-ring" problem on Springsteel's NATIVE layout: 171 cells = 513 ragged rings of 8 .. 2,052 points keeping up to
+    512 wavenumbers (SURVEY.md 8(c) "Layouts"; any num_cells is legal, src/semiimplicit.jl:155-169).  Rings with kmax > 319
+    take the chunked matrix-core DFT kernels (coefficient sets pass through the LDS in chunks of 256 wavenumbers, the
+    forward transform spreads a ring's wavenumber tiles over several workgroups); 8 levels, 2 steps against the C oracle."""
+    case = cases.rlz_hrbl(num_cells=171, zDim=8)
+    case["ts"] = 0.2
+    hip = cases.HipModel(case)
+    assert hip.run.tiles[0].N == 529416 * 8                # sum of 4 + 4 ri points over 513 rings, x 8 levels
+    orc = cases.OracleModel(case)
+    for _ in range(2):
+        hip.step()
+        orc.step()
+    _check(hip, orc, [0, 1, 318, 319, 320, 321, 400, 511, 512], "171-cell native RLZ patch (513 ragged rings, kmax up to 512) x 8 levels, 2 steps")
+
+
+def test_native_rl_patch_of_171_cells_beyond_kmax_319():
+    """The same rings without a vertical dimension (RL slab set: the MFMA columns are (variable, derivative plane) pairs)."""
+    case = cases.rl_slab(num_cells=171)
+    hip = cases.HipModel(case)
+    assert hip.run.tiles[0].N == 529416
+    orc = cases.OracleModel(case)
+    for _ in range(2):
+        hip.step()
+        orc.step()
+    _check(hip, orc, [0, 1, 319, 320, 321, 512], "171-cell native RL patch (kmax up to 512), 2 steps")
+
+
 def test_config4_full_size_forward_transform_is_linear():
     import scythe_jl_amd as S
     run = _bench_model(1)

@@ -346,11 +346,13 @@ def test_index_maps_reproduce_the_shared_sum(maker, kw, ntiles):
 
 @pytest.mark.gpu
 def test_rings_outside_every_transform_path_fail_loudly():
-    """Native rings of a 171-cell RLZ patch reach 2052 points and kmax 512: longer than the power-of-two FFT tables, beyond
-    the matrix-core DFT's kmax <= 319 and too long for the scalar kernel's LDS staging.  The library must say so - not
-    fail in a launch with 'invalid argument', and never compute something else."""
+    """Ring lengths that no azimuthal kernel can take must be refused with a clear message - not fail in a launch with
+    'invalid argument', and never compute something else.  (Native patches run up to 426 cells = rings of 5,112 points; the
+    limit left is a UNIFORM ring table that is neither a power of two <= 512 nor a multiple of 4 and too long for the scalar
+    kernel's LDS staging.)"""
     import scythe_jl_amd as S
-    gp = S.GridParameters(geometry="RLZ", xmin=0.0, xmax=3.0e5, num_cells=171, vars={"u": 1}, zmin=0.0, zmax=1.0e3, zDim=16)
+    gp = S.GridParameters(geometry="RLZ", xmin=0.0, xmax=3.0e5, num_cells=12, vars={"u": 1}, zmin=0.0, zmax=1.0e3, zDim=16,
+                          ring_uniform_L=1026)
     g = S.createGrid(gp)
     try:
         g.set_physical_values(np.zeros((g.N, 1)))
