@@ -149,9 +149,9 @@ def main():
     ap.add_argument("--tile-split", default="cost", choices=["cost", "reference"],
                     help="radial partition for N > 1: 'cost' gives the inner tiles (ring-wise kernels, ~1.6x per ring) fewer "
                          "cells; 'reference' is calcTileSizes' even split")
-    ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
-                    help="f32: derivative slots of `physical` stored as fp32 (config 5; not the headline metric, whose "
-                         "1e-10 parity bar needs fp64 throughout)")
+    ap.add_argument("--storage", default="f64", choices=["f64", "f32", "f32x"],
+                    help="f32: derivative slots of `physical` stored as fp32; f32x: also the spectral transform intermediates "
+                         "(config 5 'fp32 mixed-precision transforms'; not the headline metric, whose 1e-10 parity bar needs fp64 throughout)")
     ap.add_argument("--exchange-impl", default="lib", choices=["lib", "torch"],
                     help="N > 1: 'lib' = ncclSend/Recv/AllGather issued inside libscythe_hip.so on the tile's stream (sx_exchange), "
                          "'torch' = torch.distributed collectives on device tensors (always used with --backend gloo)")
@@ -304,7 +304,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64" if args.storage == "f64" else "f64 arithmetic and state, fp32-stored derivative planes",
+            "dtype": {"f64": "f64", "f32": "f64 arithmetic and state, fp32-stored derivative planes",
+                      "f32x": "f64 arithmetic and state, fp32-stored derivative planes and spectral transform intermediates"}[args.storage],
             "data": "synthetic",
             "config": {"workload": "RLZ %dx%dx%d (rings x azimuth x levels), 6 vars, 7 derivative slots, "
                                    "Oneway_ShallowWater_HeightResolvedBL, uniform ring table kmax<=%d, b_zDim %d"

@@ -82,7 +82,13 @@ typedef struct sx_grid_desc {
                                  src/spectralGrid.jl:12).  1: the DERIVATIVE slots of `physical` (and of the node-space
                                  transforms) are stored as fp32; the value slot, the arithmetic, every spectral array, the
                                  banded solve and the time-stepping state stay fp64, so no fp32 rounding ever enters the
-                                 model state directly - only the tendencies see it */
+                                 model state directly - only the tendencies see it.
+                                 2: additionally the SPECTRAL transform intermediates - the vertically inverted coefficients
+                                 (between the Chebyshev and the Fourier stage of tileTransform!) and the ring spectra (between
+                                 the Fourier and the B-spline stage of spectralTransform!) - are stored as fp32, every sum still
+                                 accumulated in fp64: "fp32 mixed-precision transforms".  Rounding is relative to each spectral
+                                 coefficient (6e-8), so the derivative operators do not amplify it, but it enters the state
+                                 once per step.  Uniform power-of-two ring tables with zDim 32 / 64 / 128 only. */
 } sx_grid_desc;
 
 /* ModelParameters subset the step needs (src/Scythe.jl:8-21) */

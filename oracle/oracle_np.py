@@ -460,8 +460,9 @@ def inverse_xp(grid, A, rings, cell0=0):
     for ring in rings:
         c = ring // MUBAR
         r64 = mish_points(g.xmin, g.DX, c, 1)[ring % MUBAR]                   # the Float64 gridpoint, as handed to the user
-        delta = ((XP(r64) - xm) / XP(g.DX))[None, :]
-        PH = [bspline(delta, d)[0] / XP(g.DX) ** d for d in range(3)]        # [b_rDim]
+        n0 = c                                                                # the 4 spline nodes that overlap this ring's cell: c .. c + 3
+        delta = ((XP(r64) - xm[n0:n0 + 4]) / XP(g.DX))[None, :]
+        PH = [bspline(delta, d)[0] / XP(g.DX) ** d for d in range(3)]        # [4]
         L, km = int(g.L[ring]), int(g.kmax[ring])
         nb = 1 + 2 * km
         lam = XP(g.off[ring]) + 2 * PI_X * np.arange(L, dtype=XP) / XP(L)
@@ -474,12 +475,12 @@ def inverse_xp(grid, A, rings, cell0=0):
             FI[2][:, 2 * k - 1], FI[2][:, 2 * k] = -2 * k * k * cs, 2 * k * k * sn
         phys = np.zeros((L * g.zDim, g.V, g.D), dtype=XP)
         for vi, v in enumerate(g.names):
-            Av = A[:, vi].reshape(g.b_zDim, g.K2, g.b_rDim).astype(XP)
+            Av = A[:, vi].reshape(g.b_zDim, g.K2, -1)[:, :nb, n0:n0 + 4].astype(XP)      # only what this ring reads
             if g.has_z:
                 x = g.cheb(v)._x
                 Mx = [x["T"] @ x["CA"], x["TD"] @ x["CA"], x["TDD"] @ x["CA"]]
             for d, name in enumerate(["u", "r", "rr"]):
-                coef = Av[:, :nb, :] @ PH[d]                                  # [zm, blocks]
+                coef = Av @ PH[d]                                             # [zm, blocks]
                 for ld, sname in ([(0, name)] if d > 0 else [(0, "u"), (1, "l"), (2, "ll")]):
                     if sname not in sl:
                         continue

@@ -262,6 +262,8 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->rDim = MUBAR * h->nc; h->b_rDim = h->nc + 3;
     h->uniform_L = h->has_l ? g->ring_uniform_L : 0;
     h->f32 = g->storage_f32 ? 1 : 0;
+    h->sp32 = g->storage_f32 == 2 ? 1 : 0;
+    if (g->storage_f32 < 0 || g->storage_f32 > 2) { set_error("storage_f32 must be 0, 1 or 2"); delete h; return 1; }
     h->overlap = getenv("SX_OVERLAP") ? atoi(getenv("SX_OVERLAP")) : 0;
     h->wide = !(getenv("SX_WIDE") && atoi(getenv("SX_WIDE")) == 0);
     h->sbw_prefetch = getenv("SX_SBW_PF") && atoi(getenv("SX_SBW_PF")) != 0;
@@ -480,6 +482,11 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     for (int i = 0; i < 3; i++) {
         if (!dalloc(h, &h->d_E[i], (size_t)h->V * N)) FAIL();
         if (h->semi && !dalloc(h, &h->d_I[i], (size_t)h->V * N)) FAIL();
+    }
+    if (h->sp32 && !(fft_path_ok(h) && h->has_z && (h->nz == 32 || h->nz == 64 || h->nz == 128) && h->sbw_mfma &&
+                     (h->nz <= 64 ? h->Zb <= 64 : h->Zb <= 96))) {
+        set_error("storage_f32 = 2 (fp32 spectral intermediates) needs an RLZ / RZ grid on a uniform power-of-two ring table with zDim 32, 64 or 128");
+        FAIL();
     }
     if (!dalloc(h, &h->d_Fl, (size_t)h->nrings * h->V * h->nz * h->K2)) FAIL();
     if (h->has_z) {
@@ -1135,7 +1142,7 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     if (!h || !name || !bytes) { set_error("null argument"); return 1; }
     // Algorithmic bytes per launch (fp64), counting each array once (DESIGN.md "Kernels and rooflines").
     // w = fp64; ws = width of the derivative slots of `physical` / G (4 bytes in the fp32-storage mode; value slots stay fp64)
-    const double w = 8.0, ws = h->f32 ? 4.0 : 8.0, N = (double)h->N, V = h->V;
+    const double w = 8.0, ws = h->f32 ? 4.0 : 8.0, wi = h->sp32 ? 4.0 : 8.0, N = (double)h->N, V = h->V;     // wi: Az / Fl entries
     const double S_tile = (double)h->nbt * h->C, S_patch = (double)h->b_rDim * h->C;
     const double az = h->has_z ? (double)h->nbt * h->last_zinv_jobs * h->nz * h->K2 : S_tile;
     const double fl = (double)h->nrings * h->V * h->nz * h->K2, bz = (double)h->nbt * h->V * h->nz * h->K2;
@@ -1146,21 +1153,21 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     const double eq_planes = planes(h->mask_eq_bits, h->mask_eq_val), node_planes = planes(h->mask_node_bits, h->mask_node_val);
     const bool node = h->node_mode && h->node_active;
     const double fin = node ? (double)h->R_in / h->nrings : 1.0;   // fraction of rings on the ring-wise path
-    if (k == "k_rl_inverse") b = (N * out_planes + w * az) * fin;   // write the requested physical planes, read Az
-    else if (k == "k_node_fft") b = (double)h->NG * node_planes + w * az;
+    if (k == "k_rl_inverse") b = (N * out_planes + wi * az) * fin;   // write the requested physical planes, read Az
+    else if (k == "k_node_fft") b = (double)h->NG * node_planes + wi * az;
     else if (k == "k_phys_hrbl_inner") b = N * fin * (eq_planes + w * (4.0 * V - 3.0));
     else if (k == "k_phys_hrbl" && node)                            // node transforms (read once) + history + outputs
         b = (double)h->NG * node_planes + N * (1.0 - fin) * w * (4.0 * V - 3.0);
-    else if (k == "k_zinv") b = w * (S_tile + az);
+    else if (k == "k_zinv") b = w * S_tile + wi * az;
     else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") {
         // read the requested slots, E_nm1, E_nm2; write E_n, var_np1; the SW sets also write the diagnostic w plane and
         // keep no tendency history for it
         const bool sw = (h->eq == SX_EQ_ONEWAY_SW_SLAB || h->eq == SX_EQ_TWOWAY_SW_SLAB || h->eq == SX_EQ_ONEWAY_SW_HRBL);
         b = N * (eq_planes + w * (4.0 * V + (sw ? -3.0 : 0.0)));        // inside sx_advance the diagnostic w plane is not stored
     }
-    else if (k == "k_fl_forward") b = w * (N * V + fl);
+    else if (k == "k_fl_forward") b = w * N * V + wi * fl;
     else if (k == "k_sb") b = w * (fl + bz);
-    else if (k == "k_sbz") b = w * (fl + S_tile);
+    else if (k == "k_sbz") b = wi * fl + w * S_tile;
     else if (k == "k_solve") b = w * 4.0 * S_patch;                 // read B, write y, read y, write A
     else if (k == "k_semiimplicit") b = w * N * 2.0 * 5.0;
     *bytes = b;

@@ -165,9 +165,15 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw
 
 // ------------------------------------------------------------------------------------------------ inverse
 // The output planes are `physical` or the node-space array G: value slot fp64, derivative slots ST (Planes, sx_internal.hpp)
-template <int LOGL, int COPYOUT, bool NODE, class ST>
+// (Re, Im) pair of a spectral intermediate stored as fp64 or fp32 (storage_f32 = 2), widened on load
+__device__ __forceinline__ double2 ldpair(const double *p) { return *reinterpret_cast<const double2 *>(p); }
+__device__ __forceinline__ double2 ldpair(const float *p) { const float2 v = *reinterpret_cast<const float2 *>(p); return make_double2((double)v.x, (double)v.y); }
+__device__ __forceinline__ void stpair(double *p, double2 v) { *reinterpret_cast<double2 *>(p) = v; }
+__device__ __forceinline__ void stpair(float *p, double2 v) { *reinterpret_cast<float2 *>(p) = make_float2((float)v.x, (float)v.y); }
+
+template <int LOGL, int COPYOUT, bool NODE, class ST, class AT = double>
 __global__ void __launch_bounds__(512, LOGL <= 8 ? 4 : 2)      // waves per SIMD: at L = 512 one workgroup per CU (2 x 64 KB of LDS, 4 wavenumbers per lane)
-k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
+k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,
                  int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
@@ -234,8 +240,8 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
         {
             constexpr int R = NODE ? 1 : 4;                // radial rows combined per coefficient
             const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
-            const double *a0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + (active ? za : 0))) * K2;
-            const double *b0 = a0 + ((active && hasb) ? K2 : 0);
+            const AT *a0 = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + (active ? za : 0))) * K2;
+            const AT *b0 = a0 + ((active && hasb) ? K2 : 0);
             // two wavenumbers at a time: every load of the pair first (no branches: lanes beyond the truncation read a valid
             // address and drop the value) ...
 #pragma unroll
@@ -243,10 +249,10 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                 double2 x1[R], y1[R], x2[R], y2[R];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    x1[r] = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * kcq[q0]);
-                    y1[r] = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * kcq[q0]);
-                    x2[r] = *reinterpret_cast<const double2 *>(a0 + r * azrow + 2 * kcq[q0 + 1]);
-                    y2[r] = *reinterpret_cast<const double2 *>(b0 + r * azrow + 2 * kcq[q0 + 1]);
+                    x1[r] = ldpair(a0 + r * azrow + 2 * kcq[q0]);
+                    y1[r] = ldpair(b0 + r * azrow + 2 * kcq[q0]);
+                    x2[r] = ldpair(a0 + r * azrow + 2 * kcq[q0 + 1]);
+                    y2[r] = ldpair(b0 + r * azrow + 2 * kcq[q0 + 1]);
                 }
                 if (!setup_done) {                             // ... then, once, the twiddles and phase factors behind them
                     asm volatile("" ::: "memory");
@@ -355,9 +361,9 @@ k_rl_inverse_fft(const double *__restrict__ Az, Planes<ST> phys, const double *_
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int LOGL>
+template <int LOGL, class FT = double>
 __global__ void __launch_bounds__(512)
-k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const int *__restrict__ kmaxr,
+k_fl_forward_fft(const double *__restrict__ np1, FT *__restrict__ Fl, const int *__restrict__ kmaxr,
                  const int64_t *__restrict__ pstart, const double2 *__restrict__ twg, const int64_t *__restrict__ phoff,
                  const double2 *__restrict__ ph, int V, int nz, int K2, int64_t N) {
     constexpr int L = 1 << LOGL, T = FftCfg<LOGL>::LPT, PPT = L / T;       // lanes per transform; staged pairs per thread
@@ -419,8 +425,8 @@ k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const 
     if (!active) return;
     const double2 *phr = ph + phoff[ring];
     const double inv = 1.0 / L;
-    double *oa = Fl + (((int64_t)ring * V + v) * nz + z0 + za) * K2;
-    double *ob = oa + K2;
+    FT *oa = Fl + (((int64_t)ring * V + v) * nz + z0 + za) * K2;
+    FT *ob = oa + K2;
     const bool hasb = zb < zc;
     for (int k = t; k <= km; k += T) {
         const double2 wk = X[k], wn = X[(L - k) & (L - 1)];
@@ -428,14 +434,14 @@ k_fl_forward_fft(const double *__restrict__ np1, double *__restrict__ Fl, const 
         double2 xa = make_double2(0.5 * (wk.x + wn.x), 0.5 * (wk.y - wn.y));
         double2 xb = make_double2(0.5 * (wk.y + wn.y), -0.5 * (wk.x - wn.x));
         if (k == 0) {
-            *reinterpret_cast<double2 *>(oa) = make_double2(xa.x * inv, 0.0);
-            if (hasb) *reinterpret_cast<double2 *>(ob) = make_double2(xb.x * inv, 0.0);
+            stpair(oa, make_double2(xa.x * inv, 0.0));
+            if (hasb) stpair(ob, make_double2(xb.x * inv, 0.0));
         } else {
             const double2 w = cconj(phr[k]);                        // e^{-ik off}
             xa = cmul(xa, w);
             xb = cmul(xb, w);
-            *reinterpret_cast<double2 *>(oa + 2 * k) = make_double2(xa.x * inv, xa.y * inv);
-            if (hasb) *reinterpret_cast<double2 *>(ob + 2 * k) = make_double2(xb.x * inv, xb.y * inv);
+            stpair(oa + 2 * k, make_double2(xa.x * inv, xa.y * inv));
+            if (hasb) stpair(ob + 2 * k, make_double2(xb.x * inv, xb.y * inv));
         }
     }
 }
@@ -466,18 +472,19 @@ template <int LOGL>
 static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, const double *az, int64_t azrow) {
     const int L = 1 << LOGL;
     dim3 g((h->nz + fft_fzc(L) - 1) / fft_fzc(L), tg.n_units, h->V);
-#define INV_LAUNCH(NODE, ST)                                                                                                         \
+#define INV_LAUNCH(NODE, ST, AT)                                                                                                     \
     do {                                                                                                                             \
         if (fft_lds(L, 2) > 65536)                                                                                                   \
-            HIPCHK2(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rl_inverse_fft<LOGL, 1, NODE, ST>),                         \
+            HIPCHK2(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rl_inverse_fft<LOGL, 1, NODE, ST, AT>),                     \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds(L, 2)));                           \
-        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream, az,              \
-                           planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart,                                            \
+        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST, AT>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream,              \
+                           reinterpret_cast<const AT *>(az), planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart,          \
                            h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],        \
                            h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);                                  \
     } while (0)
-    if (h->f32) { if (tg.node_mode) INV_LAUNCH(true, float); else INV_LAUNCH(false, float); }
-    else { if (tg.node_mode) INV_LAUNCH(true, double); else INV_LAUNCH(false, double); }
+    if (h->sp32) { if (tg.node_mode) INV_LAUNCH(true, float, float); else INV_LAUNCH(false, float, float); }     // storage_f32 = 2
+    else if (h->f32) { if (tg.node_mode) INV_LAUNCH(true, float, double); else INV_LAUNCH(false, float, double); }
+    else { if (tg.node_mode) INV_LAUNCH(true, double, double); else INV_LAUNCH(false, double, double); }
 #undef INV_LAUNCH
 }
 
@@ -499,8 +506,12 @@ static void launch_inv_any(sx_handle *h, const int *d_mask, const InvTarget &tg)
 template <int LOGL>
 static void launch_fwd(sx_handle *h, dim3 g) {
     const int L = 1 << LOGL;
-    hipLaunchKernelGGL(k_fl_forward_fft<LOGL>, g, dim3(fft_threads(L)), fft_lds(L), h->stream, h->d_np1, h->d_Fl, h->d_kmax,
-                       h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N);
+    if (h->sp32)
+        hipLaunchKernelGGL((k_fl_forward_fft<LOGL, float>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, h->d_np1, reinterpret_cast<float *>(h->d_Fl),
+                           h->d_kmax, h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N);
+    else
+        hipLaunchKernelGGL((k_fl_forward_fft<LOGL, double>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, h->d_np1, h->d_Fl, h->d_kmax,
+                           h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N);
 }
 
 // ring-wise inverse of the first n_rings rings of the tile (all of them by default)

@@ -129,7 +129,8 @@ struct sx_handle {
     bool in_advance = false;    // set while sx_advance launches the equation set (the diagnostic w plane is then not stored)
     bool L_all_mult4 = false;   // every ring length is a multiple of 4 (native rings are): the MFMA DFT kernels apply
     double *d_ref = nullptr;    // ReferenceState [3][3][nz] (Euler_test)
-    int f32 = 0;   // fp32 storage of d_Az, d_phys, d_G, d_Fl (allocated as raw bytes, typed by the launchers)
+    int f32 = 0;   // fp32 storage of the derivative slots of d_phys / d_G (typed by the launchers)
+    int sp32 = 0;  // storage_f32 = 2: the spectral transform intermediates d_Az and d_Fl are fp32 as well (fp64 accumulation)
     double *d_Az = nullptr, *d_phys = nullptr, *d_np1 = nullptr, *d_E[3] = {}, *d_I[3] = {};
     double *d_Fl = nullptr;
     double *d_phi = nullptr, *d_wq = nullptr;

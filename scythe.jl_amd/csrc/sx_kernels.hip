@@ -73,9 +73,9 @@ k_colmat(const double *__restrict__ in, double *__restrict__ out, const double *
 // tile is stored as 128-byte lines: no LDS, no barrier, and the scalar operator loads of k_colmat (its limiter) are gone.
 typedef double colmat_d4 __attribute__((ext_vector_type(4)));
 
-template <int MT>          // n_out / 16
+template <int MT, class OT = double>          // n_out / 16; OT = float: the fp32 spectral-intermediate mode (storage_f32 = 2)
 __global__ void __launch_bounds__(256)
-k_colmat_mfma(const double *__restrict__ in, double *__restrict__ out, const double *__restrict__ mats,
+k_colmat_mfma(const double *__restrict__ in, OT *__restrict__ out, const double *__restrict__ mats,
               const ColJob *__restrict__ jobs, int n_in, int K2, int64_t in_row, int64_t out_row, int row0) {
     constexpr int n_out = MT * 16;
     constexpr int KSTEPS = MT * 4;          // K = n_in <= n_out in steps of 4, fully unrolled (rows beyond n_in contribute zeros)
@@ -86,7 +86,7 @@ k_colmat_mfma(const double *__restrict__ in, double *__restrict__ out, const dou
     const int blk = min(blk0 + n, K2 - 1);
     const ColJob job = jobs[blockIdx.y];
     const double *src = in + (int64_t)(row0 + blockIdx.z) * in_row + job.in_off + blk;
-    double *dst = out + (int64_t)blockIdx.z * out_row + job.out_off;
+    OT *dst = out + (int64_t)blockIdx.z * out_row + job.out_off;
     const double *MTr = mats + job.mat_off;                // operator transposed: [n_in][n_out]
     // Every B element (coefficient row k, block n) of this wave is requested before the first MFMA, and each tile's operator
     // fragments (L2-resident) before that tile's chain: with the loads inside the K loop every step of 4 waited for its own
@@ -112,7 +112,7 @@ k_colmat_mfma(const double *__restrict__ in, double *__restrict__ out, const dou
             if (4 * ks < n_in) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
         if (okc) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) dst[(int64_t)(t * 16 + kk + 4 * r) * K2 + blk0 + n] = acc[r];
+            for (int r = 0; r < 4; r++) dst[(int64_t)(t * 16 + kk + 4 * r) * K2 + blk0 + n] = (OT)acc[r];
         }
     }
 }
@@ -456,9 +456,9 @@ k_sbw(const double *__restrict__ Fl, double *__restrict__ B, const double *__res
 // BW = wavenumber blocks per workgroup: 64 (zDim 32 / 64), or 32 for zDim 128, where the operator fragments (6 row tiles x
 // 32 K steps = 96 KB) and the node tile (128 levels x 32 blocks) have to share the 160 KB; then wave w owns column tile
 // w & 1 and the row tiles (w >> 1), (w >> 1) + 4.
-template <int NZ, int BW = 64, int THREADS = 512>
+template <int NZ, int BW = 64, int THREADS = 512, class FT = double>      // FT = float: fp32-stored ring spectra (storage_f32 = 2)
 __global__ void __launch_bounds__(THREADS, 2)
-k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *__restrict__ phi, const double *__restrict__ wq,
+k_sbw_mfma(const FT *__restrict__ Fl, double *__restrict__ B, const double *__restrict__ phi, const double *__restrict__ wq,
            const double *__restrict__ CB, int ncells, int V, int Zb, int K2, int64_t C, int cps) {
     constexpr int NG = THREADS / BW;                  // level groups: thread = (group g, block lb), levels z = g + NG i
     constexpr int ZPT = NZ / NG, KS = NZ / 4, LS = BW + 16;      // LS: the 4 levels a K step reads fall in disjoint bank halves
@@ -474,7 +474,7 @@ k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *
     const int cend = (cb == ncells) ? ncells + 3 : cb;          // the last segment also owns the 3 trailing nodes
     const int cstart = max(0, ca - 3);
     const int64_t plane = (int64_t)V * NZ * K2;
-    const double *base = Fl + ((int64_t)v * NZ + g) * K2 + (ok ? blk : 0);
+    const FT *base = Fl + ((int64_t)v * NZ + g) * K2 + (ok ? blk : 0);
     // operator fragments: A[m][k] = CB[m][k], lane supplies m = 16 mt + (lane & 15), k = 4 js + (lane >> 4)
     const int MT = (Zb + 15) / 16, mhalf = (MT + 1) / 2;
     // this wave's column tile nt and row tiles mt0, mt1 (nmt of them)
@@ -497,12 +497,12 @@ k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *
     for (int q = 0; q < 4; q++)
 #pragma unroll
         for (int i = 0; i < ZPT; i++) acc[q][i] = 0.0;
-    double xn[MUBAR][ZPT];
+    FT xn[MUBAR][ZPT];
     auto fetch = [&](int c) {
         if (c < cstart || c >= cend || c >= ncells) return;
 #pragma unroll
         for (int mu = 0; mu < MUBAR; mu++) {
-            const double *src = base + (int64_t)(c * MUBAR + mu) * plane;
+            const FT *src = base + (int64_t)(c * MUBAR + mu) * plane;
 #pragma unroll
             for (int i = 0; i < ZPT; i++) xn[mu][i] = __builtin_nontemporal_load(src + (int64_t)(NG * i) * K2);
         }
@@ -526,10 +526,11 @@ k_sbw_mfma(const double *__restrict__ Fl, double *__restrict__ B, const double *
                     const double w2 = w * phi[(int64_t)ring * 4 + 2], w3 = w * phi[(int64_t)ring * 4 + 3];
 #pragma unroll
                     for (int i = 0; i < ZPT; i++) {
-                        acc[u][i] += w0 * xn[mu][i];
-                        acc[(u + 1) & 3][i] += w1 * xn[mu][i];
-                        acc[(u + 2) & 3][i] += w2 * xn[mu][i];
-                        acc[(u + 3) & 3][i] += w3 * xn[mu][i];
+                        const double xv = (double)xn[mu][i];
+                        acc[u][i] += w0 * xv;
+                        acc[(u + 1) & 3][i] += w1 * xv;
+                        acc[(u + 2) & 3][i] += w2 * xv;
+                        acc[(u + 3) & 3][i] += w3 * xv;
                     }
                 }
                 fetch(c + 1);           // in flight while node c goes through LDS and the matrix cores
@@ -1746,9 +1747,11 @@ void launch_zinv(sx_handle *h, bool full) {
         dim3 g((h->K2 + 63) / 64, njobs, h->nbt);
         const ColJob *jobs = full ? h->d_jobs_zinv_full : h->d_jobs_zinv_eq;
         const int64_t azrow = (int64_t)h->V * 3 * h->nz * h->K2;
-        if (h->nz == 64) hipLaunchKernelGGL(k_colmat_mfma<4>, g, dim3(256), 0, h->stream, h->d_A, h->d_Az, h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0);
-        else if (h->nz == 32) hipLaunchKernelGGL(k_colmat_mfma<2>, g, dim3(256), 0, h->stream, h->d_A, h->d_Az, h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0);
-        else if (h->nz == 128) hipLaunchKernelGGL(k_colmat_mfma<8>, g, dim3(256), 0, h->stream, h->d_A, h->d_Az, h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0);
+#define ZINV(MT, OT) hipLaunchKernelGGL((k_colmat_mfma<MT, OT>), g, dim3(256), 0, h->stream, h->d_A, reinterpret_cast<OT *>(h->d_Az), h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0)
+        if (h->nz == 64) { if (h->sp32) ZINV(4, float); else ZINV(4, double); }
+        else if (h->nz == 32) { if (h->sp32) ZINV(2, float); else ZINV(2, double); }
+        else if (h->nz == 128) { if (h->sp32) ZINV(8, float); else ZINV(8, double); }
+#undef ZINV
         else
             hipLaunchKernelGGL(k_colmat, g, dim3(64, 4), sizeof(double) * 64 * h->Zb, h->stream, h->d_A, h->d_Az, h->d_Mz, jobs,
                                h->Zb, h->nz, h->K2, h->C, azrow, h->cell0);
@@ -2002,6 +2005,12 @@ void launch_sb(sx_handle *h) {
             auto kern = h->nz == 64 ? (pf ? k_sbw<64, true> : k_sbw<64, false>) : h->nz == 32 ? (pf ? k_sbw<32, true> : k_sbw<32, false>) : k_sbw<128, false>;
             if (mf) kern = h->nz == 64 ? k_sbw_mfma<64> : h->nz == 32 ? k_sbw_mfma<32> : k_sbw_mfma<128, 32>;
             if (t256) kern = k_sbw_mfma<64, 32, 256>;
+            if (h->sp32) {             // fp32-stored ring spectra (storage_f32 = 2; sx_create guarantees the matrix-core kernel applies)
+                auto kf = t256 ? k_sbw_mfma<64, 32, 256, float> : h->nz == 64 ? k_sbw_mfma<64, 64, 512, float>
+                          : h->nz == 32 ? k_sbw_mfma<32, 64, 512, float> : k_sbw_mfma<128, 32, 512, float>;
+                hipLaunchKernelGGL(kf, gw, dim3(t256 ? 256 : 512), 0, h->stream, reinterpret_cast<const float *>(h->d_Fl), h->d_Btile, h->d_phi,
+                                   h->d_wq, h->d_CB, h->ncells, h->V, h->Zb, h->K2, h->C, cps);
+            } else
             hipLaunchKernelGGL(kern, gw, dim3(t256 ? 256 : 512), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->d_CB, h->ncells,
                                h->V, h->Zb, h->K2, h->C, cps);
             HIPCHK(hipGetLastError());

@@ -92,7 +92,8 @@ class GridParameters:
     # extensions (not in the reference): uniform ring table and a separate k = 0 inner BC
     ring_uniform_L: int = 0
     BCL_k0: Optional[Dict] = None
-    storage: str = "f64"       # "f32": physical and the transform intermediates are stored as fp32 (sx_grid_desc.storage_f32)
+    storage: str = "f64"       # "f32": derivative slots of `physical` stored as fp32; "f32x": also the spectral transform
+                               # intermediates (sx_grid_desc.storage_f32 = 1 / 2)
 
     def __post_init__(self):
         if self.rDim is None:
@@ -155,9 +156,9 @@ def grid_desc(patch: GridParameters, tile_cell0=0, tile_num_cells=None, tile_num
     d.tile_cell0 = tile_cell0
     d.tile_num_cells = patch.num_cells if tile_num_cells is None else tile_num_cells
     d.tile_num = tile_num
-    if patch.storage not in ("f64", "f32"):
-        raise ValueError("GridParameters.storage must be 'f64' or 'f32'")
-    d.storage_f32 = 1 if patch.storage == "f32" else 0
+    if patch.storage not in ("f64", "f32", "f32x"):
+        raise ValueError("GridParameters.storage must be 'f64', 'f32' or 'f32x'")
+    d.storage_f32 = {"f64": 0, "f32": 1, "f32x": 2}[patch.storage]
     return d, keep
 
 

@@ -266,6 +266,14 @@ def config2_literal(twoway=False):
                 eq="Twoway_ShallowWater_Slab" if twoway else "Oneway_ShallowWater_Slab", ts=3.0, par=par, ic=ic)
 
 
+def config5_case():
+    """SURVEY.md 8(d) config 5 at its full size: 341 cells -> 1023 rings x 512 azimuthal points x 128 levels, HRBL set
+    (bench.py --workload rlz_1023x512x128)."""
+    case = rlz_hrbl(num_cells=341, zDim=128, ring_L=512)
+    case["ts"] = 0.02                    # bench.TS_OF: 0.3 m end spacing of the 128-level Chebyshev column
+    return case
+
+
 def config3_rz(num_cells=171, zDim=128):
     """configs[2]: RZ 513 x 128 with Chebyshev vertical (b_zDim = zDim) and the semi-implicit adjustment.
 
@@ -300,9 +308,16 @@ def slot_errors_vs_extended(g, phys, A, rings):
     the inverse transform of the SAME Float64 coefficients A evaluated in extended precision (oracle_np.inverse_xp) and
     scale is rel_err_per_var's (slot scale floored by the operator gain times the variable's magnitude).
     This measures the rounding error of one implementation's tileTransform!; it does not depend on any other one."""
+    pts = {r: ring_points(g, [r]) for r in rings}
+    return slot_errors_vs_extended_rings(g, {r: phys[pts[r]] for r in rings}, A, rings)
+
+
+def slot_errors_vs_extended_rings(g, ring_phys, A, rings):
+    """slot_errors_vs_extended with the evaluated fields given ring by ring ({ring: [L * zDim, V, D]}) - for grids whose
+    whole `physical` array is never formed on the host (config 5)."""
     truth = O.inverse_xp(g, A, rings)
     t = np.concatenate([truth[r] for r in rings], axis=0)
-    a = phys[ring_points(g, rings)]
+    a = np.concatenate([ring_phys[r] for r in rings], axis=0)
     t64 = np.asarray(t, dtype=np.float64)
     vmax = [max(np.abs(t64[:, v, 0]).max(), 1e-300) for v in range(a.shape[1])]
     out = np.zeros(a.shape[2])

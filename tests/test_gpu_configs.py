@@ -292,6 +292,78 @@ def test_config5_full_size_f32_storage_finite_and_close_to_f64_storage():
     b.close()
 
 
+@pytest.mark.skipif(not os.environ.get("SCYTHE_SLOW_TESTS"), reason="a MEASUREMENT (4 minutes, 45 GB of host arrays), recorded in "
+                    "profiles/r03/config5_f32x_full_size_20_steps.txt: fp32 transform intermediates miss the declared bars at 128 levels")
+def test_config5_full_size_fp32_spectral_intermediates_20_steps():
+    """BASELINE.json configs[4] / SURVEY.md 8(d) item 5 at FULL size over 20 steps: storage "f32x" (fp32-stored derivative planes
+    AND fp32-stored transform intermediates - vertically inverted coefficients, ring spectra - with fp64 accumulation)
+    against the all-fp64 run of the same library.  Declared: fields within 1e-6 of each variable's scale, every derivative
+    slot (tileTransform! after the 20 steps) within 5e-5 of the slot's scale.  It does not hold them (see the 64-level
+    case in tests/test_gpu_parity.py for the mechanism); run with SCYTHE_SLOW_TESTS=1 to reproduce the numbers."""
+    a = _bench_model(1, workload=C5, storage="f32x")
+    b = _bench_model(1, workload=C5, storage="f64")
+    for _ in range(20):
+        a.step()
+        b.step()
+    fa, fb = _np1_fields(a), _np1_fields(b)
+    err = _max_rel(fa, fb)
+    del fa, fb
+    # derivative slots on sampled rings (the whole physical array is 22 GB per run)
+    worst = np.zeros(7)
+    ga, gb = a.tiles[0], b.tiles[0]
+    ga.tileTransform_()
+    gb.tileTransform_()
+    pa, pb = ga.physical, gb.physical
+    g = cases.oracle_grid(cases.config5_case())
+    idx = cases.ring_points(g, [0, 1, 253, 254, 600, 1022])
+    worst = cases.per_slot_errors(pa[idx], pb[idx])
+    print("\nconfig 5 full size, 20 steps, fp32 spectral intermediates vs all-fp64: fields %.2e; slots on sampled rings %s"
+          % (err, " ".join("%.1e" % x for x in worst)))
+    assert 0.0 < err < 1e-6, err
+    assert worst[0] < 1e-6 and (worst < 5e-5).all(), worst
+    a.close()
+    b.close()
+
+
+def test_config5_full_size_against_the_sampled_oracle_fixture():
+    """Config 5 at FULL size (RLZ 1023 x 512 x 128, 67 M points, all-fp64 storage), 2 steps, against the C oracle's full-size
+    run as sampled by tests/golden/make_config5_fixture.py (run once in the build container; committed: tests/golden/
+    config5_sampled.npz).  (1) STATE: the A coefficients of 48 (z-mode, wavenumber) columns, all radial nodes, to 1e-10 of
+    the variable's largest coefficient; (2) VALUES on sampled points of cells 0 / 84 / 85 / 340 to 1e-10; (3) every
+    DERIVATIVE slot on rings 0 / 253 / 254 / 256 / 1022 by check_full's criterion - the HIP path's error against the
+    EXTENDED-precision evaluation of its own coefficients is no larger than twice the fp64 oracle's against its own."""
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "config5_sampled.npz"))
+    case = cases.config5_case()
+    assert case["ts"] == float(fx["ts"])
+    hip = cases.HipModel(case)
+    tile = hip.run.tiles[0]
+    assert tile.N == 1023 * 512 * 128
+    for _ in range(int(fx["steps"])):
+        hip.step()
+    assert not tile.check_nan()
+    g = cases.oracle_grid(case)
+    A = np.asarray(hip.A)
+    eA = 0.0
+    for i, (zm, blk) in enumerate(fx["cols"]):
+        for v in range(g.V):
+            got = A[:, v].reshape(g.b_zDim, g.K2, g.b_rDim)[zm, blk]
+            eA = max(eA, float(np.abs(got - fx["A_cols"][i, :, v]).max() / fx["A_scale"][v]))
+    tile.tileTransform_()
+    phys = tile.physical
+    got = phys[fx["pt_idx"]]
+    ref, sc = fx["pt_val"], fx["pt_scale"]
+    e_pts = np.array([max(float(np.abs(got[:, v, d] - ref[:, v, d]).max() / sc[v, d]) for v in range(g.V) if sc[v, d] > 0)
+                      for d in range(g.D)])
+    rings = [int(r) for r in fx["rings"]]
+    e_hip = cases.slot_errors_vs_extended_rings(g, {r: phys[cases.ring_points(g, [r])] for r in rings}, A, rings)
+    e_orc = fx["e_orc"]
+    cases.report_slots("config 5 at full size (RLZ 1023 x 512 x 128, fp64), 2 steps (A coefficients %.1e on 48 columns)" % eA, g,
+                       [("HIP vs extended precision (own A)", e_hip), ("fp64 oracle vs extended precision (own A; fixture)", e_orc),
+                        ("HIP vs fp64 oracle, sampled points", e_pts)])
+    assert eA < TOL and e_pts[0] < TOL, (eA, e_pts)
+    assert (e_hip <= 2.0 * e_orc + 2e-15).all(), (e_hip, e_orc)
+
+
 @pytest.mark.skipif(not os.environ.get("SCYTHE_SLOW_TESTS"), reason="5 minutes (the C oracle steps 67 M points at 7 s per step): "
                     "run with SCYTHE_SLOW_TESTS=1; last result in profiles/r02/config5_full_size_state_parity.txt")
 def test_config5_full_size_state_against_the_c_oracle():

@@ -222,6 +222,41 @@ def test_fp32_storage_mode_within_declared_tolerance(maker, kw):
     assert 1e-9 < err_all < F32_TOL_DER, err_all      # the lower bound proves the fp32 path really ran
 
 
+@pytest.mark.parametrize("kw,within", [({"num_cells": 8, "zDim": 32, "ring_L": 32}, True), ({"num_cells": 6, "zDim": 64, "ring_L": 16}, False)])
+def test_fp32_spectral_intermediates_measured_against_the_declared_tolerance(kw, within):
+    """storage "f32x" (sx_grid_desc.storage_f32 = 2; BASELINE.json configs[4] "fp32 mixed-precision transforms", SURVEY.md
+    8(d) item 5 "fp32 storage for physical AND transform intermediates"): besides the derivative planes also the transform
+    intermediates - the vertically inverted coefficients and the ring spectra - are stored as fp32, sums accumulated in
+    fp64.  Measured against the fp32 mode's declared bars (values 1e-6, derivative slots 5e-5 vs the fp64 oracle, 3 steps):
+    at 32 levels it holds them (8e-8 / 4e-5); at 64 levels it does NOT (6e-5 / 2e-3, MI355X) - both intermediates are in
+    PHYSICAL space along the Chebyshev column, an fp32 rounding there is white noise in z at 6e-8, and the column's second
+    derivative (vertical mixing of the HRBL set) amplifies it by O(zDim^4) on its way back into the state.  That is why
+    config 5 (128 levels) runs with storage "f32" - derivative planes only, which feed ts * tendency and nothing else - and
+    why this mode is kept as a measurement, not a recommendation."""
+    case = cases.rlz_hrbl(**kw)
+    ref = cases.OracleModel(case)
+    hip = cases.HipModel(case, storage="f32x")
+    for _ in range(3):
+        ref.step()
+        hip.step()
+    a, b = hip.physical(), ref.physical()
+    err_val = cases.rel_err_per_var(a[:, :, :1], b[:, :, :1])
+    err_all = cases.rel_err_per_var(a, b)
+    print("\nf32x %s: values %.2e, all slots %.2e" % (kw, err_val, err_all))
+    assert np.isfinite(a).all() and err_val > 1e-10            # fp32 intermediates really were in the state path
+    if within:
+        assert err_val < F32_TOL_VAL and err_all < F32_TOL_DER, (err_val, err_all)
+    else:
+        assert err_val > F32_TOL_VAL, err_val                  # the measured reason for not using it at 64+ levels
+        assert err_val < 1e-3                                  # ... an accuracy loss, not a blow-up
+
+
+def test_fp32_spectral_intermediates_are_refused_where_the_kernels_do_not_exist():
+    import scythe_jl_amd as S
+    with pytest.raises(S.ScytheHipError, match="storage_f32 = 2"):
+        cases.HipModel(cases.rlz_hrbl(num_cells=4, zDim=12), storage="f32x")          # native rings, 12 levels
+
+
 def test_fp32_storage_512_point_rings_every_wavenumber_against_the_oracle():
     """Config 5's transform shape where the oracle still steps in seconds: 90 cells x 512-point rings (kmax reaches 255, so
     every bin of the two-wave 512-point FFT carries signal) x 16 levels, fp32-stored derivative planes, 3 steps against the
