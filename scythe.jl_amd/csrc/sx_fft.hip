@@ -29,10 +29,12 @@ namespace sx {
 // arrive as whole 128-byte lines (8 levels per workgroup - 64-byte pieces - held the L = 512 kernels at 3.2 TB/s).
 // SKEW: complex elements between transform regions (bank spreading when L < 256; 0 at L = 512 so that the two LDS sets
 // of the inverse are exactly 64 KB).
-template <int LOGL> struct FftCfg {
+// HL = 1 halves the lanes per transform (two butterflies per lane and pass already at L = 256: 256-thread workgroups whose
+// waves carry twice the independent work; used by the inverse kernels, see launch_inv).
+template <int LOGL, int HL = 0> struct FftCfg {
     static constexpr int FZC = 16, FNP = FZC / 2, LOGZ = 4, SKEW = (LOGL <= 8) ? 2 : 0;
     static constexpr int L4 = (1 << LOGL) / 4;
-    static constexpr int LPT = L4 > 64 ? 64 : L4;      // lanes per transform
+    static constexpr int LPT = (L4 > 64 ? 64 : L4) >> HL;      // lanes per transform
     static constexpr int NB = L4 / LPT;                // radix-4 butterflies per lane and pass
     static constexpr int NK = 2 * NB;                  // wavenumbers (k < L / 2) per lane
 };
@@ -66,21 +68,25 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-template <int LOGL>
+template <int LOGL, int HL = 0>
 struct Twiddles {
-    static constexpr int L = 1 << LOGL, NP4 = LOGL / 2, LPT = FftCfg<LOGL>::LPT, NB = FftCfg<LOGL>::NB;
-    double2 w1[NP4 > 1 ? NP4 - 1 : 1];     // w2 = w1^2, w3 = w1^3 are formed on the fly (registers are the scarce resource)
+    static constexpr int L = 1 << LOGL, NP4 = LOGL / 2, LPT = FftCfg<LOGL, HL>::LPT, NB = FftCfg<LOGL, HL>::NB;
+    double2 w1[NP4 > 1 ? NP4 - 1 : 1][NB]; // w2 = w1^2, w3 = w1^3 are formed on the fly (registers are the scarce resource)
     double2 r2[2 * NB];                    // final radix-2 pass (odd log2 L): butterflies j = t + c LPT
     // SIGN = +1: e^{+i...} (inverse), -1: forward.  t = lane within the transform.  The radix-4 twiddle of butterfly
-    // j = t + b LPT depends on j mod Ns only, and Ns <= LPT in every radix-4 pass, so all NB butterflies of a lane share it.
+    // j = t + b LPT depends on j mod Ns only: while Ns <= LPT all NB butterflies of a lane share it ([p][0]; the other
+    // entries are never touched and cost no register), a pass with Ns > LPT keeps one per butterfly.
     template <int SIGN>
     __device__ void init(const double2 *__restrict__ twg, int t) {
         int Ns = 4;
 #pragma unroll
         for (int p = 1; p < NP4; p++) {
-            const int s = (t & (Ns - 1)) * (L / (4 * Ns));
-            w1[p - 1] = twg[s];
-            if (SIGN < 0) w1[p - 1].y = -w1[p - 1].y;
+#pragma unroll
+            for (int b = 0; b < (Ns > LPT ? NB : 1); b++) {
+                const int s = ((t + b * LPT) & (Ns - 1)) * (L / (4 * Ns));
+                w1[p - 1][b] = twg[s];
+                if (SIGN < 0) w1[p - 1][b].y = -w1[p - 1][b].y;
+            }
             Ns <<= 2;
         }
         if (LOGL & 1) {
@@ -101,9 +107,9 @@ struct NoSink {
 };
 
 // TO_LDS = true: the final pass is written back to X as well (natural order), `last` is not called.
-template <int LOGL, int SIGN, bool TO_LDS = false, class F = NoSink>
-__device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw, int t, bool active, F last = F()) {
-    constexpr int L = 1 << LOGL, NBF = L / 4, NP4 = LOGL / 2, LPT = FftCfg<LOGL>::LPT, NB = FftCfg<LOGL>::NB;
+template <int LOGL, int SIGN, bool TO_LDS = false, class F = NoSink, int HL = 0>
+__device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL, HL> &tw, int t, bool active, F last = F()) {
+    constexpr int L = 1 << LOGL, NBF = L / 4, NP4 = LOGL / 2, LPT = FftCfg<LOGL, HL>::LPT, NB = FftCfg<LOGL, HL>::NB;
     int Ns = 1;
 #pragma unroll
     for (int p = 0; p < NP4; p++) {
@@ -116,7 +122,7 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL> &tw
                 const int j = t + b * LPT;
                 double2 v0 = X[j], v1 = X[j + NBF], v2 = X[j + 2 * NBF], v3 = X[j + 3 * NBF];
                 if (p > 0) {
-                    const double2 w1 = tw.w1[p - 1], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+                    const double2 w1 = tw.w1[p - 1][Ns > LPT ? b : 0], w2 = cmul(w1, w1), w3 = cmul(w2, w1);
                     v1 = cmul(v1, w1); v2 = cmul(v2, w2); v3 = cmul(v3, w3);
                 }
                 const double2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), t3 = cmuli(csub(v1, v3), SIGN);
@@ -171,8 +177,10 @@ __device__ __forceinline__ double2 ldpair(const float *p) { const float2 v = *re
 __device__ __forceinline__ void stpair(double *p, double2 v) { *reinterpret_cast<double2 *>(p) = v; }
 __device__ __forceinline__ void stpair(float *p, double2 v) { *reinterpret_cast<float2 *>(p) = make_float2((float)v.x, (float)v.y); }
 
-template <int LOGL, int COPYOUT, bool NODE, class ST, class AT = double>
-__global__ void __launch_bounds__(512, LOGL <= 8 ? 4 : 2)      // waves per SIMD: at L = 512 one workgroup per CU (2 x 64 KB of LDS, 4 wavenumbers per lane)
+// HL / SETS: lanes per transform halved (256-thread workgroups at L = 256) / LDS sets (2: the copy-out of a slot overlaps the
+// next slot's transform inside the workgroup; 1: half the LDS, the overlap comes from more workgroups per CU instead)
+template <int LOGL, int COPYOUT, bool NODE, class ST, class AT = double, int HL = 0, int SETS = 2>
+__global__ void __launch_bounds__(512 >> HL, HL ? 3 : LOGL <= 8 ? 4 : 2)      // waves per SIMD: at L = 512 one workgroup per CU (2 x 64 KB of LDS, 4 wavenumbers per lane)
 k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,
@@ -180,8 +188,8 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                  int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz) {
     // NODE: the "rings" are radial NODES (uniform ring tables only): one Az row per unit, no radial combination;
     // the output is the node-space array G that the equation-set kernel combines with the basis weights itself.
-    constexpr int L = 1 << LOGL, T = FftCfg<LOGL>::LPT, NK = FftCfg<LOGL>::NK;
-    constexpr int FZC = FftCfg<LOGL>::FZC, FNP = FftCfg<LOGL>::FNP, LOGZ = FftCfg<LOGL>::LOGZ, SKEW = FftCfg<LOGL>::SKEW;
+    constexpr int L = 1 << LOGL, T = FftCfg<LOGL, HL>::LPT, NK = FftCfg<LOGL, HL>::NK;
+    constexpr int FZC = FftCfg<LOGL, HL>::FZC, FNP = FftCfg<LOGL, HL>::FNP, LOGZ = FftCfg<LOGL, HL>::LOGZ, SKEW = FftCfg<LOGL, HL>::SKEW;
     extern __shared__ double2 smf[];
     FFT_STAMP(0);
     int nslot = 0;
@@ -207,7 +215,7 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
     // twiddles and phase factors are fetched BEHIND the first group's coefficient loads (below): the memory counter retires
     // in issue order, and the coefficients are what the first transform waits for.  (Phase stamps: a third of a
     // workgroup's time used to pass before its first transform started - three dependent round trips.)
-    Twiddles<LOGL> tw;
+    Twiddles<LOGL, HL> tw;
     bool setup_done = false;
     const int j0 = NODE ? ring : ring / MUBAR;
     const double2 *phr = ph + phoff[ring];
@@ -284,9 +292,10 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
         for (int ld = 0; ld < 3; ld++) {
             if (!(ld == 0 ? n0 : ld == 1 ? n1 : n2)) continue;
             const int slot = ld == 0 ? sl0 : ld == 1 ? sl1 : sl2;
-            double2 *set = smf + (COPYOUT ? par * FNP * (L + SKEW) : 0);
+            double2 *set = smf + ((COPYOUT && SETS == 2) ? par * FNP * (L + SKEW) : 0);
             double2 *X = set + f * (L + SKEW);
             par ^= 1;
+            if (COPYOUT && SETS == 1 && nslot > 0) lds_barrier();     // the previous slot's copy-out has read this (only) set
             if (active) {
 #pragma unroll
                 for (int q = 0; q < NK; q++) {
@@ -307,7 +316,7 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
             wave_sync();
             if (COPYOUT) {
                 // last pass goes back to LDS, then the whole workgroup writes full 128-byte lines
-                fft_inplace<LOGL, +1, true>(X, tw, t, active);
+                fft_inplace<LOGL, +1, true, NoSink, HL>(X, tw, t, active);
                 if (nslot == 0) FFT_STAMP(2); else if (nslot == 1) FFT_STAMP(5);
                 lds_barrier();       // also orders the previous slot's copy-out reads (other set) before that set is restaged
                 if (nslot == 0) FFT_STAMP(3);
@@ -343,7 +352,7 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                 nslot++;
             } else {
                 const int64_t o0 = p0 * nz + z0 + za;
-                fft_inplace<LOGL, +1>(X, tw, t, active, [&](int l, double2 y) {
+                auto sink = [&](int l, double2 y) {
                     if (slot == 0) {
                         double *o = phys.val + (int64_t)v * N + o0 + (int64_t)l * nz;
                         if (pair_ok && hasb) *reinterpret_cast<double2 *>(o) = y;
@@ -352,7 +361,8 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                         ST *o = phys.der + ((int64_t)(slot - 1) * V + v) * N + o0 + (int64_t)l * nz;
                         o[0] = (ST)y.x; if (hasb) o[1] = (ST)y.y;
                     }
-                });
+                };
+                fft_inplace<LOGL, +1, false, decltype(sink), HL>(X, tw, t, active, sink);
                 wave_sync();      // the region is rewritten by the next slot
             }
         }
@@ -456,7 +466,7 @@ bool fft_path_ok(const sx_handle *h) {
 
 static int fft_fzc(int) { return 16; }
 static size_t fft_lds(int L, int sets = 1) { return sizeof(double2) * (size_t)sets * (fft_fzc(L) / 2) * (L + (L <= 256 ? 2 : 0)); }
-static int fft_threads(int L) { return std::max(64, (fft_fzc(L) / 2) * std::min(L / 4, 64)); }       // FNP transforms x LPT lanes
+static int fft_threads(int L, int hl = 0) { return std::max(64, (fft_fzc(L) / 2) * (std::min(L / 4, 64) >> hl)); }       // FNP transforms x LPT lanes
 
 struct InvTarget {          // where an inverse ring launch writes and which unit tables it uses
     double *out;            // physical [slot][v][N] or node-space G [slot][v][NG]
@@ -472,20 +482,31 @@ template <int LOGL>
 static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, const double *az, int64_t azrow) {
     const int L = 1 << LOGL;
     dim3 g((h->nz + fft_fzc(L) - 1) / fft_fzc(L), tg.n_units, h->V);
-#define INV_LAUNCH(NODE, ST, AT)                                                                                                     \
+    // A/B knob of the measurements in DESIGN.md 4: SX_FFT_VARIANT = 0: 64 lanes per transform, two LDS sets (512 threads);
+    // 1: 32 lanes per transform, ONE set (256 threads, 33 KB: three workgroups per CU); 2: 32 lanes, two sets
+    static const int variant_env = getenv("SX_FFT_VARIANT") ? atoi(getenv("SX_FFT_VARIANT")) : 0;
+    const int variant = (LOGL == 8) ? variant_env : 0;
+#define INV_LAUNCH_V(NODE, ST, AT, HL, SETS)                                                                                         \
     do {                                                                                                                             \
-        if (fft_lds(L, 2) > 65536)                                                                                                   \
-            HIPCHK2(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rl_inverse_fft<LOGL, 1, NODE, ST, AT>),                     \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds(L, 2)));                           \
-        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST, AT>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream,              \
+        if (fft_lds(L, SETS) > 65536)                                                                                                \
+            HIPCHK2(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rl_inverse_fft<LOGL, 1, NODE, ST, AT, HL, SETS>),           \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds(L, SETS)));                        \
+        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST, AT, HL, SETS>), g, dim3(fft_threads(L, HL)), fft_lds(L, SETS), h->stream, \
                            reinterpret_cast<const AT *>(az), planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart,          \
                            h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],        \
                            h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);                                  \
+    } while (0)
+#define INV_LAUNCH(NODE, ST, AT)                                                                                                     \
+    do {                                                                                                                             \
+        if (LOGL == 8 && variant == 1) INV_LAUNCH_V(NODE, ST, AT, (LOGL == 8 ? 1 : 0), 1);                                           \
+        else if (LOGL == 8 && variant == 2) INV_LAUNCH_V(NODE, ST, AT, (LOGL == 8 ? 1 : 0), 2);                                      \
+        else INV_LAUNCH_V(NODE, ST, AT, 0, 2);                                                                                       \
     } while (0)
     if (h->sp32) { if (tg.node_mode) INV_LAUNCH(true, float, float); else INV_LAUNCH(false, float, float); }     // storage_f32 = 2
     else if (h->f32) { if (tg.node_mode) INV_LAUNCH(true, float, double); else INV_LAUNCH(false, float, double); }
     else { if (tg.node_mode) INV_LAUNCH(true, double, double); else INV_LAUNCH(false, double, double); }
 #undef INV_LAUNCH
+#undef INV_LAUNCH_V
 }
 
 static void launch_inv_any(sx_handle *h, const int *d_mask, const InvTarget &tg) {

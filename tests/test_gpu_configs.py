@@ -351,9 +351,7 @@ def test_config5_full_size_against_the_sampled_oracle_fixture():
     tile.tileTransform_()
     phys = tile.physical
     got = phys[fx["pt_idx"]]
-    ref, sc = fx["pt_val"], fx["pt_scale"]
-    e_pts = np.array([max(float(np.abs(got[:, v, d] - ref[:, v, d]).max() / sc[v, d]) for v in range(g.V) if sc[v, d] > 0)
-                      for d in range(g.D)])
+    e_pts = cases.per_slot_errors(got, fx["pt_val"])       # slot scale floored by the operator gain x the variable's magnitude
     rings = [int(r) for r in fx["rings"]]
     e_hip = cases.slot_errors_vs_extended_rings(g, {r: phys[cases.ring_points(g, [r])] for r in rings}, A, rings)
     e_orc = fx["e_orc"]
