@@ -115,7 +115,6 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL, HL>
     for (int p = 0; p < NP4; p++) {
         double2 y0[NB], y1[NB], y2[NB], y3[NB];
         int j0[NB];
-        const int k = t & (Ns - 1);
         if (active) {
 #pragma unroll
             for (int b = 0; b < NB; b++) {
@@ -127,6 +126,7 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL, HL>
                 }
                 const double2 t0 = cadd(v0, v2), t1 = csub(v0, v2), t2 = cadd(v1, v3), t3 = cmuli(csub(v1, v3), SIGN);
                 y0[b] = cadd(t0, t2); y1[b] = cadd(t1, t3); y2[b] = csub(t0, t2); y3[b] = csub(t1, t3);
+                const int k = j & (Ns - 1);        // = t & (Ns - 1) while Ns <= LPT
                 j0[b] = ((j - k) << 2) + k;
             }
         }
@@ -178,7 +178,9 @@ __device__ __forceinline__ void stpair(double *p, double2 v) { *reinterpret_cast
 __device__ __forceinline__ void stpair(float *p, double2 v) { *reinterpret_cast<float2 *>(p) = make_float2((float)v.x, (float)v.y); }
 
 // HL / SETS: lanes per transform halved (256-thread workgroups at L = 256) / LDS sets (2: the copy-out of a slot overlaps the
-// next slot's transform inside the workgroup; 1: half the LDS, the overlap comes from more workgroups per CU instead)
+// next slot's transform inside the workgroup; 1: half the LDS, the overlap comes from more workgroups per CU instead).
+// Only (0, 2) is launched: measured at the bench grid (round 3) HL = 1 with one set 0.148 / 0.153 ms (node / ring-wise), with two
+// sets 0.160 / 0.173 ms, against 0.130 / 0.135 ms - 168 VGPRs with 18-40 spilled registers at three waves per SIMD.
 template <int LOGL, int COPYOUT, bool NODE, class ST, class AT = double, int HL = 0, int SETS = 2>
 __global__ void __launch_bounds__(512 >> HL, HL ? 3 : LOGL <= 8 ? 4 : 2)      // waves per SIMD: at L = 512 one workgroup per CU (2 x 64 KB of LDS, 4 wavenumbers per lane)
 k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
@@ -482,10 +484,6 @@ template <int LOGL>
 static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, const double *az, int64_t azrow) {
     const int L = 1 << LOGL;
     dim3 g((h->nz + fft_fzc(L) - 1) / fft_fzc(L), tg.n_units, h->V);
-    // A/B knob of the measurements in DESIGN.md 4: SX_FFT_VARIANT = 0: 64 lanes per transform, two LDS sets (512 threads);
-    // 1: 32 lanes per transform, ONE set (256 threads, 33 KB: three workgroups per CU); 2: 32 lanes, two sets
-    static const int variant_env = getenv("SX_FFT_VARIANT") ? atoi(getenv("SX_FFT_VARIANT")) : 0;
-    const int variant = (LOGL == 8) ? variant_env : 0;
 #define INV_LAUNCH_V(NODE, ST, AT, HL, SETS)                                                                                         \
     do {                                                                                                                             \
         if (fft_lds(L, SETS) > 65536)                                                                                                \
@@ -496,12 +494,7 @@ static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, con
                            h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],        \
                            h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);                                  \
     } while (0)
-#define INV_LAUNCH(NODE, ST, AT)                                                                                                     \
-    do {                                                                                                                             \
-        if (LOGL == 8 && variant == 1) INV_LAUNCH_V(NODE, ST, AT, (LOGL == 8 ? 1 : 0), 1);                                           \
-        else if (LOGL == 8 && variant == 2) INV_LAUNCH_V(NODE, ST, AT, (LOGL == 8 ? 1 : 0), 2);                                      \
-        else INV_LAUNCH_V(NODE, ST, AT, 0, 2);                                                                                       \
-    } while (0)
+#define INV_LAUNCH(NODE, ST, AT) INV_LAUNCH_V(NODE, ST, AT, 0, 2)
     if (h->sp32) { if (tg.node_mode) INV_LAUNCH(true, float, float); else INV_LAUNCH(false, float, float); }     // storage_f32 = 2
     else if (h->f32) { if (tg.node_mode) INV_LAUNCH(true, float, double); else INV_LAUNCH(false, float, double); }
     else { if (tg.node_mode) INV_LAUNCH(true, double, double); else INV_LAUNCH(false, double, double); }
