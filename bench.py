@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 HBM_ACHIEVABLE_GBS = 6300.0   # same guide: 6.29 TB/s measured for a float4 copy (79 % of spec)
-PROFILE_ROUND = "r02"     # profiles/<round>/pmc_traffic_<workload>.json: the PMC passes of the current build
+PROFILE_ROUND = "r03"     # profiles/<round>/pmc_traffic_<workload>.json: the PMC passes of the current build
 
 WORKLOADS = {
     # name: (num_cells, ring_L, zDim)

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Collect a round's profiles on the GPU box:  gpurun -- 'bash profiles/collect.sh r02 v1'
+# Collect a round's profiles on the GPU box:  gpurun -- 'bash profiles/collect.sh r03 v1'
 # 1) rocprofv3 --kernel-trace --stats of bench.py; 2)+3) separate --pmc FETCH_SIZE / WRITE_SIZE passes (kernel-trace
 # only, as MI355X_MICROARCH.md prescribes); 4) per-kernel HBM bytes (summarize_pmc.py, with the library's sha256);
 # 5) the un-profiled default bench line.  Results land under gpurun_out/prof/<round>/ and are copied from there into
 # profiles/<round>/ (see profiles/README.md).
 set -e
-ROUND=${1:-r02}; TAG=${2:-v1}
+ROUND=${1:-r03}; TAG=${2:-v1}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof/$ROUND; mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-native"
