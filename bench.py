@@ -221,12 +221,19 @@ def main():
             impl = "torch (lib failed: %s)" % err
             run = make_run("torch")
         if impl == "lib" and not args.no_selfcheck:
-            # both implementations of the exchange, two steps each from the same initial condition: same fields
-            other = make_run("torch")
+            # both implementations of the exchange, two steps each from the same initial condition: same fields.  One after
+            # the other with a device-wide wait in between: the library's communicator and torch's are never in flight at
+            # the same time (two communicators whose kernels meet in different orders on different ranks can deadlock)
             for _ in range(2):
                 run.step()
+            torch.cuda.synchronize()
+            a = run.tiles[0].var_np1
+            dist.barrier()
+            other = make_run("torch")
+            for _ in range(2):
                 other.step()
-            a, b = run.tiles[0].var_np1, other.tiles[0].var_np1
+            torch.cuda.synchronize()
+            b = other.tiles[0].var_np1
             selfcheck = float(max(np.abs(a[:, v] - b[:, v]).max() / max(np.abs(b[:, v]).max(), 1e-300) for v in range(a.shape[1])))
             other.close()
             del other, a, b
