@@ -266,6 +266,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     if (g->storage_f32 < 0 || g->storage_f32 > 2) { set_error("storage_f32 must be 0, 1 or 2"); delete h; return 1; }
     h->overlap = getenv("SX_OVERLAP") ? atoi(getenv("SX_OVERLAP")) : 0;
     h->wide = !(getenv("SX_WIDE") && atoi(getenv("SX_WIDE")) == 0);
+    h->fuse_zinv = getenv("SX_FUSE_ZINV") && atoi(getenv("SX_FUSE_ZINV")) != 0;
     h->sbw_prefetch = getenv("SX_SBW_PF") && atoi(getenv("SX_SBW_PF")) != 0;
     h->sbw_mfma = !(getenv("SX_SBW_MFMA") && atoi(getenv("SX_SBW_MFMA")) == 0);
     h->cell0 = g->tile_cell0; h->ncells = g->tile_num_cells; h->tile_num = g->tile_num;
@@ -1144,7 +1145,9 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     // w = fp64; ws = width of the derivative slots of `physical` / G (4 bytes in the fp32-storage mode; value slots stay fp64)
     const double w = 8.0, ws = h->f32 ? 4.0 : 8.0, wi = h->sp32 ? 4.0 : 8.0, N = (double)h->N, V = h->V;     // wi: Az / Fl entries
     const double S_tile = (double)h->nbt * h->C, S_patch = (double)h->b_rDim * h->C;
-    const double az = h->has_z ? (double)h->nbt * h->last_zinv_jobs * h->nz * h->K2 : S_tile;
+    const bool fusedz = h->node_mode && h->node_active && fft_fused_zinv(h);       // node-space units invert vertically inside their FFT kernel
+    const int zrows = h->last_zinv_rows > 0 || fusedz ? h->last_zinv_rows : h->nbt;
+    const double az = h->has_z ? (double)zrows * h->last_zinv_jobs * h->nz * h->K2 : S_tile;
     const double fl = (double)h->nrings * h->V * h->nz * h->K2, bz = (double)h->nbt * h->V * h->nz * h->K2;
     std::string k(name);
     double b = 0;
@@ -1154,11 +1157,11 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     const bool node = h->node_mode && h->node_active;
     const double fin = node ? (double)h->R_in / h->nrings : 1.0;   // fraction of rings on the ring-wise path
     if (k == "k_rl_inverse") b = (N * out_planes + wi * az) * fin;   // write the requested physical planes, read Az
-    else if (k == "k_node_fft") b = (double)h->NG * node_planes + wi * az;
+    else if (k == "k_node_fft") b = (double)h->NG * node_planes + (fusedz ? w * S_tile : wi * (double)h->nbt * h->last_zinv_jobs * h->nz * h->K2);
     else if (k == "k_phys_hrbl_inner") b = N * fin * (eq_planes + w * (4.0 * V - 3.0));
     else if (k == "k_phys_hrbl" && node)                            // node transforms (read once) + history + outputs
         b = (double)h->NG * node_planes + N * (1.0 - fin) * w * (4.0 * V - 3.0);
-    else if (k == "k_zinv") b = w * S_tile + wi * az;
+    else if (k == "k_zinv") b = w * S_tile * zrows / h->nbt + wi * az;
     else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") {
         // read the requested slots, E_nm1, E_nm2; write E_n, var_np1; the SW sets also write the diagnostic w plane and
         // keep no tendency history for it

@@ -181,13 +181,19 @@ __device__ __forceinline__ void stpair(float *p, double2 v) { *reinterpret_cast<
 // next slot's transform inside the workgroup; 1: half the LDS, the overlap comes from more workgroups per CU instead).
 // Only (0, 2) is launched: measured at the bench grid (round 3) HL = 1 with one set 0.148 / 0.153 ms (node / ring-wise), with two
 // sets 0.160 / 0.173 ms, against 0.130 / 0.135 ms - 168 VGPRs with 18-40 spilled registers at three waves per SIMD.
-template <int LOGL, int COPYOUT, bool NODE, class ST, class AT = double, int HL = 0, int SETS = 2>
+// FUSE (node mode, L <= 256, b_zDim <= 64): the vertical inverse runs INSIDE this kernel - the workgroup forms its
+// [16 levels x K2] coefficient slab as Mz[v][sz][16 x b_zDim] . A[node][v][b_zDim x K2] on the f64 matrix cores (8 waves x 2
+// column tiles of 16 wavenumber blocks, operands straight from L2), through the LDS set the next slot is about to stage,
+// into the lanes' registers; `Az` of the node-space units is never written or read (k_zinv then only serves the ring-wise rings).
+typedef double fft_d4 __attribute__((ext_vector_type(4)));
+template <int LOGL, int COPYOUT, bool NODE, class ST, class AT = double, int HL = 0, int SETS = 2, bool FUSE = false>
 __global__ void __launch_bounds__(512 >> HL, HL ? 3 : LOGL <= 8 ? 4 : 2)      // waves per SIMD: at L = 512 one workgroup per CU (2 x 64 KB of LDS, 4 wavenumbers per lane)
 k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,
                  int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
-                 int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz) {
+                 int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz,
+                 const double *__restrict__ Asrc = nullptr, int64_t Astride = 0, const double *__restrict__ MzT = nullptr, int Zb = 0) {
     // NODE: the "rings" are radial NODES (uniform ring tables only): one Az row per unit, no radial combination;
     // the output is the node-space array G that the equation-set kernel combines with the basis weights itself.
     constexpr int L = 1 << LOGL, T = FftCfg<LOGL, HL>::LPT, NK = FftCfg<LOGL, HL>::NK;
@@ -247,6 +253,67 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
         const bool n0 = sl0 >= 0 && ((mask >> sl0) & 1), n1 = sl1 >= 0 && ((mask >> sl1) & 1), n2 = sl2 >= 0 && ((mask >> sl2) & 1);
         if (!n0 && !n1 && !n2) continue;
         double2 aq[NK], bq[NK];
+        if (FUSE) {
+            // vertical inverse of this group's operator on the matrix cores: D[level][block] = sum_zm Mz[level][zm] A[zm][block]
+            constexpr int KSM = 16, NWV = (FNP * T) / 64 > 0 ? (FNP * T) / 64 : 1;                 // K steps (b_zDim <= 64); waves of the workgroup
+            constexpr int TPW = ((L / 16 > 0 ? L / 16 : 1) + NWV - 1) / NWV;                        // column tiles (16 wavenumber blocks) per wave
+            constexpr int SST = 2 * (L + SKEW) * FNP / FZC;      // row stride (doubles) of the slab: the set's 16-byte elements as 16 rows
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n16 = lane & 15, kk4 = lane >> 4;
+            double *S = reinterpret_cast<double *>(smf + ((COPYOUT && SETS == 2) ? par * FNP * (L + SKEW) : 0));
+            const double *arow = Asrc + (int64_t)j0 * Astride + (int64_t)v * Zb * K2;
+            const double *mop = MzT + ((int64_t)v * 3 + sz) * Zb * nz + z0 + n16;
+            constexpr int KH = 8;                              // operands in halves of 8 K steps: 32 VGPRs live instead of 64
+#pragma unroll
+            for (int tt = 0; tt < TPW; tt++) {
+                const int tile = wave * TPW + tt;
+                const int blk = min(tile * 16 + n16, K2 - 1);
+                fft_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                // operand addresses walk forward by 4 rows per K step from an OPAQUE start: formed here, per tile and group
+                // (as invariants of the group loop the 64 of them were hoisted and spilled)
+                int64_t oa = (int64_t)kk4 * nz, ob = (int64_t)kk4 * K2 + blk;
+                asm volatile("" : "+v"(oa), "+v"(ob));
+                const double *pa = mop + oa, *pb = arow + ob;
+#pragma unroll
+                for (int k0 = 0; k0 < KSM; k0 += KH) {
+                    if (4 * k0 >= Zb) break;
+                    double am[KH], bm[KH];
+#pragma unroll
+                    for (int ks = 0; ks < KH; ks++) {
+                        const int k = 4 * (k0 + ks) + kk4;
+                        am[ks] = k < Zb ? *pa : 0.0;
+                        bm[ks] = (k < Zb && tile * 16 < K2) ? *pb : 0.0;
+                        pa += 4 * (int64_t)nz; pb += 4 * (int64_t)K2;
+                    }
+                    if (!setup_done) {                         // twiddles behind the first operands (see below)
+                        asm volatile("" ::: "memory");
+                        int tt2 = t;
+                        asm volatile("" : "+v"(tt2));
+                        tw.template init<+1>(twg, tt2);
+                        asm volatile("" ::: "memory");
+                        setup_done = true;
+                    }
+#pragma unroll
+                    for (int ks = 0; ks < KH; ks++)
+                        if (4 * (k0 + ks) < Zb) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(am[ks], bm[ks], acc, 0, 0, 0);
+                }
+                if (tile * 16 < K2) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) S[(kk4 + 4 * r) * SST + tile * 16 + n16] = acc[r];
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int q = 0; q < NK; q++) {
+                double2 a1 = make_double2(0.0, 0.0), b1 = a1;
+                if (active && inq[q]) {
+                    a1 = *reinterpret_cast<const double2 *>(S + za * SST + 2 * kcq[q]);
+                    if (hasb) b1 = *reinterpret_cast<const double2 *>(S + zb * SST + 2 * kcq[q]);
+                }
+                if (kq[q] == 0) { a1.y = 0.0; b1.y = 0.0; }
+                aq[q] = a1; bq[q] = b1;
+            }
+            lds_barrier();      // every lane holds its coefficients before the slab's set is staged
+        } else
         {
             constexpr int R = NODE ? 1 : 4;                // radial rows combined per coefficient
             const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
@@ -466,6 +533,16 @@ bool fft_path_ok(const sx_handle *h) {
     return h->has_l && L >= 16 && L <= 512 && (L & (L - 1)) == 0;   // one transform = min(L/4, 64) lanes of one wave
 }
 
+// SX_FUSE_ZINV=1: node-space units take the vertical inverse inside the inverse FFT kernel (FUSE): 16-level chunks, b_zDim <= 64
+// (16 K steps of the f64 MFMA), rings of at most 256 points (two column tiles per wave), fp64 intermediates.  OFF by default -
+// measured at the bench grid (round 3, A/B/A/B on one box): k_zinv 0.065 -> 0.024 ms (it then only serves the ring-wise
+// rings), Az of the 174 nodes never written or read, but k_node_fft 0.131 -> 0.201 ms: 968 against 987 steps/s.  The
+// matrix-core prologue (per coefficient group four rounds of 16 L2 loads -> 8 MFMAs at the 128 registers the kernel has, an
+// LDS round trip and two workgroup barriers) is serial time in a kernel whose limit is its serial time.
+bool fft_fused_zinv(const sx_handle *h) {
+    return h->fuse_zinv && h->node_mode && h->has_z && h->uniform_L <= 256 && h->Zb <= 64 && h->nz % 16 == 0 && !h->sp32;
+}
+
 static int fft_fzc(int) { return 16; }
 static size_t fft_lds(int L, int sets = 1) { return sizeof(double2) * (size_t)sets * (fft_fzc(L) / 2) * (L + (L <= 256 ? 2 : 0)); }
 static int fft_threads(int L, int hl = 0) { return std::max(64, (fft_fzc(L) / 2) * (std::min(L / 4, 64) >> hl)); }       // FNP transforms x LPT lanes
@@ -495,9 +572,16 @@ static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, con
                            h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);                                  \
     } while (0)
 #define INV_LAUNCH(NODE, ST, AT) INV_LAUNCH_V(NODE, ST, AT, 0, 2)
-    if (h->sp32) { if (tg.node_mode) INV_LAUNCH(true, float, float); else INV_LAUNCH(false, float, float); }     // storage_f32 = 2
+#define INV_LAUNCH_FUSED(ST)                                                                                                         \
+    hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, true, ST, double, 0, 2, true>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream,  \
+                       az, planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart, h->d_tw, tg.phoff, h->d_ph, d_mask, h->V,   \
+                       h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4],       \
+                       h->slot[5], h->slot[6], h->d_A + (int64_t)h->cell0 * h->C, h->C, h->d_MzT, h->Zb)
+    if (tg.node_mode && fft_fused_zinv(h)) { if (LOGL <= 8) { if (h->f32) INV_LAUNCH_FUSED(float); else INV_LAUNCH_FUSED(double); } }
+    else if (h->sp32) { if (tg.node_mode) INV_LAUNCH(true, float, float); else INV_LAUNCH(false, float, float); }     // storage_f32 = 2
     else if (h->f32) { if (tg.node_mode) INV_LAUNCH(true, float, double); else INV_LAUNCH(false, float, double); }
     else { if (tg.node_mode) INV_LAUNCH(true, double, double); else INV_LAUNCH(false, double, double); }
+#undef INV_LAUNCH_FUSED
 #undef INV_LAUNCH
 #undef INV_LAUNCH_V
 }

@@ -122,6 +122,7 @@ struct sx_handle {
     int n_dft_items[3] = {0, 0, 0};
     int n_dft_big[3] = {0, 0, 0};            // of which (listed first) rings with kmax > DFT_KMAX_SINGLE: chunked kernels
     int dft_lcap_small = 0, dft_kcap_small = 0;   // largest ring length / kmax among the other rings
+    int fuse_zinv = 0;      // SX_FUSE_ZINV=1: vertical inverse inside the node FFT kernel (measured slower: sx_fft.hip)
     int sbw_mfma = 1;       // k_sbw_mfma (matrix-core vertical contraction, operator in registers) for zDim 64 / 32 (SX_SBW_MFMA=0: k_sbw)
     int sbw_prefetch = 0;   // k_sbw requests the next cell's ring spectra before contracting the current node (SX_SBW_PF=0: off)
     int wide = 1;    // 16-byte-per-lane loads / stores in the equation-set kernels (SX_WIDE=0: the 8-byte forms, A/B timing)
@@ -162,7 +163,7 @@ struct sx_handle {
     int *d_nkmax = nullptr, *d_mask_node = nullptr;
     int64_t *d_npstart = nullptr, *d_nphoff = nullptr;
     sx::ColJob *d_jobs_zinv_full = nullptr, *d_jobs_zinv_eq = nullptr, *d_jobs_zf = nullptr;
-    int njobs_zinv_full = 0, njobs_zinv_eq = 0, last_zinv_jobs = 0;
+    int njobs_zinv_full = 0, njobs_zinv_eq = 0, last_zinv_jobs = 0, last_zinv_rows = 0;
     int ncls = 0;
     size_t dev_bytes = 0;
     std::vector<void *> allocs;
@@ -180,6 +181,7 @@ namespace sx {
 void launch_zinv(sx_handle *h, bool full);
 void launch_rl_inverse(sx_handle *h, bool full);
 bool fft_path_ok(const sx_handle *h);
+bool fft_fused_zinv(const sx_handle *h);
 bool dft_mfma_ok(const sx_handle *h);
 void launch_rl_inverse_dft(sx_handle *h, const int *d_mask);
 void launch_fl_forward_dft(sx_handle *h);

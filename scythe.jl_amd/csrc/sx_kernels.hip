@@ -1744,7 +1744,12 @@ void launch_zinv(sx_handle *h, bool full) {
     const int njobs = full ? h->njobs_zinv_full : h->njobs_zinv_eq;
     h->last_zinv_jobs = njobs;
     if (njobs > 0) {
-        dim3 g((h->K2 + 63) / 64, njobs, h->nbt);
+        // inside sx_advance on uniform rings the node-space units invert vertically inside their FFT kernel (sx_fft.hip, FUSE):
+        // Az is then needed only for the nodes the ring-wise inner rings read (cells [0, R_in / 3) -> nodes 0 .. R_in / 3 + 2)
+        const int rows = (!full && h->node_mode && fft_fused_zinv(h)) ? (h->R_in > 0 ? std::min(h->nbt, h->R_in / MUBAR + 3) : 0) : h->nbt;
+        h->last_zinv_rows = rows;
+        if (rows == 0) { timer_end(h); return; }
+        dim3 g((h->K2 + 63) / 64, njobs, rows);
         const ColJob *jobs = full ? h->d_jobs_zinv_full : h->d_jobs_zinv_eq;
         const int64_t azrow = (int64_t)h->V * 3 * h->nz * h->K2;
 #define ZINV(MT, OT) hipLaunchKernelGGL((k_colmat_mfma<MT, OT>), g, dim3(256), 0, h->stream, h->d_A, reinterpret_cast<OT *>(h->d_Az), h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0)

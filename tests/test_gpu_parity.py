@@ -107,6 +107,14 @@ def test_node_space_inverse_equals_ring_wise_inverse(monkeypatch, zDim, ring_L):
     assert cases.rel_err_per_var(a.physical(), b.physical()) < 1e-11
 
 
+def test_vertical_inverse_fused_into_the_node_fft_gives_the_same_fields(monkeypatch):
+    """SX_FUSE_ZINV=1 (off by default: measured slower): the node-space units form their coefficient slabs on the
+    matrix cores inside the inverse FFT kernel instead of reading k_zinv's output - same fields as the oracle."""
+    monkeypatch.setenv("SX_FUSE_ZINV", "1")
+    for kw in ({"num_cells": 8, "zDim": 32, "ring_L": 32}, {"num_cells": 6, "zDim": 64, "ring_L": 256}):
+        assert _run(cases.rlz_hrbl(**kw), 3) < TOL
+
+
 def test_rlz_hrbl_native_rings_on_the_matrix_core_dft():
     """Native ragged rings with >= 8 levels take the f64-MFMA truncated-DFT kernels (sx_dft.hip): 90 rings of 8..364
     points, four launch classes, partial level chunk (zDim 20)."""
