@@ -180,14 +180,15 @@ __device__ __forceinline__ void stpair(float *p, double2 v) { *reinterpret_cast<
 // HL / SETS: lanes per transform halved (256-thread workgroups at L = 256) / LDS sets (2: the copy-out of a slot overlaps the
 // next slot's transform inside the workgroup; 1: half the LDS, the overlap comes from more workgroups per CU instead).
 // Only (0, 2) is launched: measured at the bench grid (round 3) HL = 1 with one set 0.148 / 0.153 ms (node / ring-wise), with two
-// sets 0.160 / 0.173 ms, against 0.130 / 0.135 ms - 168 VGPRs with 18-40 spilled registers at three waves per SIMD.
+// sets 0.160 / 0.173 ms, against 0.130 / 0.135 ms - 168 VGPRs with 18-40 spilled registers at three waves per SIMD; at 512 points
+// (config 5) the node kernel with ONE set and 128 registers (two workgroups per CU instead of one): 1.60 against 1.22 ms.
 // FUSE (node mode, L <= 256, b_zDim <= 64): the vertical inverse runs INSIDE this kernel - the workgroup forms its
 // [16 levels x K2] coefficient slab as Mz[v][sz][16 x b_zDim] . A[node][v][b_zDim x K2] on the f64 matrix cores (8 waves x 2
 // column tiles of 16 wavenumber blocks, operands straight from L2), through the LDS set the next slot is about to stage,
 // into the lanes' registers; `Az` of the node-space units is never written or read (k_zinv then only serves the ring-wise rings).
 typedef double fft_d4 __attribute__((ext_vector_type(4)));
 template <int LOGL, int COPYOUT, bool NODE, class ST, class AT = double, int HL = 0, int SETS = 2, bool FUSE = false>
-__global__ void __launch_bounds__(512 >> HL, HL ? 3 : LOGL <= 8 ? 4 : 2)      // waves per SIMD: at L = 512 one workgroup per CU (2 x 64 KB of LDS, 4 wavenumbers per lane)
+__global__ void __launch_bounds__(512 >> HL, HL ? 3 : (LOGL <= 8 || SETS == 1) ? 4 : 2)      // waves per SIMD: at L = 512 one workgroup per CU with two LDS sets (2 x 64 KB, 4 wavenumbers per lane), two with one set
 k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,

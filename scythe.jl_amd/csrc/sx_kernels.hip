@@ -73,7 +73,10 @@ k_colmat(const double *__restrict__ in, double *__restrict__ out, const double *
 // tile is stored as 128-byte lines: no LDS, no barrier, and the scalar operator loads of k_colmat (its limiter) are gone.
 typedef double colmat_d4 __attribute__((ext_vector_type(4)));
 
-template <int MT, class OT = double>          // n_out / 16; OT = float: the fp32 spectral-intermediate mode (storage_f32 = 2)
+// CT = column tiles (16 wavenumber blocks each) per wave: a tile's operator fragments are fetched once per wave and row tile
+// and serve CT column tiles.  At 128 levels every wave pulls the whole 87 KB operator through L2 (6.7 GB per step at config 5
+// with CT = 1, three times the kernel's HBM bytes): CT = 2 there.
+template <int MT, class OT = double, int CT = 1>          // n_out / 16; OT = float: the fp32 spectral-intermediate mode (storage_f32 = 2)
 __global__ void __launch_bounds__(256)
 k_colmat_mfma(const double *__restrict__ in, OT *__restrict__ out, const double *__restrict__ mats,
               const ColJob *__restrict__ jobs, int n_in, int K2, int64_t in_row, int64_t out_row, int row0) {
@@ -81,23 +84,25 @@ k_colmat_mfma(const double *__restrict__ in, OT *__restrict__ out, const double 
     constexpr int KSTEPS = MT * 4;          // K = n_in <= n_out in steps of 4, fully unrolled (rows beyond n_in contribute zeros)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = lane & 15, kk = lane >> 4;
-    const int blk0 = (blockIdx.x * 4 + wave) * 16;
+    const int blk0 = (blockIdx.x * 4 + wave) * 16 * CT;
     if (blk0 >= K2) return;
-    const int blk = min(blk0 + n, K2 - 1);
     const ColJob job = jobs[blockIdx.y];
-    const double *src = in + (int64_t)(row0 + blockIdx.z) * in_row + job.in_off + blk;
+    const double *src = in + (int64_t)(row0 + blockIdx.z) * in_row + job.in_off;
     OT *dst = out + (int64_t)blockIdx.z * out_row + job.out_off;
     const double *MTr = mats + job.mat_off;                // operator transposed: [n_in][n_out]
     // Every B element (coefficient row k, block n) of this wave is requested before the first MFMA, and each tile's operator
     // fragments (L2-resident) before that tile's chain: with the loads inside the K loop every step of 4 waited for its own
     // round trip (11 in a row at b_zDim 43).
-    double b[KSTEPS];
+    double b[CT][KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) {
-        const int k = 4 * ks + kk;
-        b[ks] = (k < n_in) ? src[(int64_t)k * K2] : 0.0;
+    for (int c = 0; c < CT; c++) {
+        const int blk = min(blk0 + c * 16 + n, K2 - 1);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+            const int k = 4 * ks + kk;
+            b[c][ks] = (k < n_in) ? src[(int64_t)k * K2 + blk] : 0.0;
+        }
     }
-    const bool okc = blk0 + n < K2;
 #pragma unroll
     for (int t = 0; t < MT; t++) {
         double a[KSTEPS];
@@ -106,13 +111,16 @@ k_colmat_mfma(const double *__restrict__ in, OT *__restrict__ out, const double 
             const int k = 4 * ks + kk;
             a[ks] = (k < n_in) ? MTr[(int64_t)k * n_out + t * 16 + n] : 0.0;      // A[m = lane & 15][k], 128-byte rows
         }
-        colmat_d4 acc = colmat_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ks++)
-            if (4 * ks < n_in) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[ks], acc, 0, 0, 0);
-        if (okc) {
+        for (int c = 0; c < CT; c++) {
+            colmat_d4 acc = colmat_d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 4; r++) dst[(int64_t)(t * 16 + kk + 4 * r) * K2 + blk0 + n] = (OT)acc[r];
+            for (int ks = 0; ks < KSTEPS; ks++)
+                if (4 * ks < n_in) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b[c][ks], acc, 0, 0, 0);
+            if (blk0 + c * 16 + n < K2) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) dst[(int64_t)(t * 16 + kk + 4 * r) * K2 + blk0 + c * 16 + n] = (OT)acc[r];
+            }
         }
     }
 }
@@ -1749,13 +1757,18 @@ void launch_zinv(sx_handle *h, bool full) {
         const int rows = (!full && h->node_mode && fft_fused_zinv(h)) ? (h->R_in > 0 ? std::min(h->nbt, h->R_in / MUBAR + 3) : 0) : h->nbt;
         h->last_zinv_rows = rows;
         if (rows == 0) { timer_end(h); return; }
-        dim3 g((h->K2 + 63) / 64, njobs, rows);
+        static const int ct_env = getenv("SX_ZINV_CT") ? atoi(getenv("SX_ZINV_CT")) : 0;      // A/B: column tiles per wave at 128 levels
+        const int ct = h->nz == 128 ? (ct_env > 0 ? ct_env : 2) : (h->nz == 64 && ct_env == 2 ? 2 : 1);
+        dim3 g((h->K2 + 64 * ct - 1) / (64 * ct), njobs, rows);
         const ColJob *jobs = full ? h->d_jobs_zinv_full : h->d_jobs_zinv_eq;
         const int64_t azrow = (int64_t)h->V * 3 * h->nz * h->K2;
-#define ZINV(MT, OT) hipLaunchKernelGGL((k_colmat_mfma<MT, OT>), g, dim3(256), 0, h->stream, h->d_A, reinterpret_cast<OT *>(h->d_Az), h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0)
-        if (h->nz == 64) { if (h->sp32) ZINV(4, float); else ZINV(4, double); }
-        else if (h->nz == 32) { if (h->sp32) ZINV(2, float); else ZINV(2, double); }
-        else if (h->nz == 128) { if (h->sp32) ZINV(8, float); else ZINV(8, double); }
+#define ZINV(MT, OT, CT) hipLaunchKernelGGL((k_colmat_mfma<MT, OT, CT>), g, dim3(256), 0, h->stream, h->d_A, reinterpret_cast<OT *>(h->d_Az), h->d_MzT, jobs, h->Zb, h->K2, h->C, azrow, h->cell0)
+        if (h->nz == 64 && ct == 2) { if (h->sp32) ZINV(4, float, 2); else ZINV(4, double, 2); }
+        else if (h->nz == 64) { if (h->sp32) ZINV(4, float, 1); else ZINV(4, double, 1); }
+        else if (h->nz == 32) { if (h->sp32) ZINV(2, float, 1); else ZINV(2, double, 1); }
+        else if (h->nz == 128 && ct == 1) { if (h->sp32) ZINV(8, float, 1); else ZINV(8, double, 1); }
+        else if (h->nz == 128 && ct == 4) { if (h->sp32) ZINV(8, float, 4); else ZINV(8, double, 4); }
+        else if (h->nz == 128) { if (h->sp32) ZINV(8, float, 2); else ZINV(8, double, 2); }
 #undef ZINV
         else
             hipLaunchKernelGGL(k_colmat, g, dim3(64, 4), sizeof(double) * 64 * h->Zb, h->stream, h->d_A, h->d_Az, h->d_Mz, jobs,
