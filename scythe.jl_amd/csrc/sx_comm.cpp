@@ -35,12 +35,18 @@ static Rccl *rccl() {
     static bool tried = false;
     if (tried) return r.lib ? &r : nullptr;
     tried = true;
-    const char *names[] = {getenv("SX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    // a copy that is already mapped (e.g. the one PyTorch ships) wins: one RCCL per process
-    for (const char *n : names)
-        if (n && !r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    for (const char *n : names)
-        if (n && !r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    if (const char *forced = getenv("SX_RCCL_LIB")) {
+        // an explicit choice is final (also over a copy PyTorch has already mapped): another RCCL build, or the stand-in
+        // transport of the tests (tests/fake_rccl.cpp)
+        r.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        // a copy that is already mapped (e.g. the one PyTorch ships) wins: one RCCL per process
+        for (const char *n : names)
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        for (const char *n : names)
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
     if (!r.lib) { set_error(std::string("librccl not found: ") + dlerror()); return nullptr; }
 #define BIND(field, sym)                                                                  \
     *(void **)(&r.field) = dlsym(r.lib, sym);                                             \

@@ -180,3 +180,61 @@ def test_bench_cli_two_ranks_rccl():
         d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
         assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange_impl"] == "lib"
         assert d["config"]["exchange_selfcheck_max_rel_diff"] < 1e-12
+
+
+# ----------------------------------------------------------------------------- the in-library exchange with MORE THAN ONE rank
+def _fake_worker(rank, world, lib_path, uid, exchange, case_name, case_kw, q):
+    """One process = one tile = one rank of sx_comm_init / sx_exchange; no torch.distributed anywhere: the only thing the ranks
+    share is the 128-byte id, as in the Julia host of INTEGRATION.md 4."""
+    os.environ["SX_RCCL_LIB"] = lib_path            # before the library binds its transport
+    import scythe_jl_amd as S
+    from tests import cases
+    case = getattr(cases, case_name)(**case_kw)
+    gp, mp_ = cases.hip_params(case)
+    run = S.ModelRun(mp_, num_tiles=world, rank=rank, device="cuda", use_dist=True, exchange=exchange, impl="lib", unique_id=uid)
+    tile = run.tiles[0]
+    pts = S.getGridpoints(tile)
+    run.set_initial_conditions([case["ic"](pts.reshape(len(pts), -1))])
+    for _ in range(3):
+        run.step()
+    phys = run.physical()
+    orc = cases.OracleModel(case)
+    for _ in range(3):
+        orc.step()
+    ref = orc.physical()
+    p0 = sum(int(run.layout.tile_sizes[4, t]) for t in range(rank))
+    q.put((rank, float(cases.rel_err_per_var(phys, ref[p0:p0 + tile.N]))))
+    run.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("exchange,world,case_name,case_kw", [
+    ("iface", 2, "rlz_hrbl", {"num_cells": 18, "zDim": 12, "ring_L": 32}),
+    ("iface", 4, "rlz_hrbl", {"num_cells": 36, "zDim": 32, "ring_L": 16}),
+    ("iface", 3, "kat_r", {"num_cells": 40}),                                  # PERIODIC: wrap-around rows between the first and the last rank
+    ("a2a", 3, "rlz_hrbl", {"num_cells": 14, "zDim": 12, "ring_L": 32}),
+    ("gather", 3, "rl_slab", {"num_cells": 12}),
+])
+def test_in_library_exchange_multi_rank_through_a_stand_in_transport(tmp_path, exchange, world, case_name, case_kw):
+    """sx_comm_init / sx_exchange with 2-4 RANKS IN SEPARATE PROCESSES on the one GPU: every rank-dependent branch of the
+    in-library exchange (csrc/sx_comm.cpp: offsets by rank, the grouped send / receive loops to every peer, the halo chain
+    rank -> rank + 1, the in-place all-gather) against the one-patch oracle.  RCCL refuses two ranks on one device, so the
+    library is pointed (SX_RCCL_LIB) at tests/fake_rccl.cpp, a stand-in with RCCL's entry points that moves the messages
+    through shared memory - it validates this library's use of the API, not RCCL or xGMI."""
+    import subprocess
+    lib = str(tmp_path / "libfake_rccl.so")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-o", lib, os.path.join(root, "tests", "fake_rccl.cpp"), "-lrt"],
+                   check=True, capture_output=True)
+    uid = ("/sxfake_%d_%s" % (os.getpid(), os.urandom(4).hex())).encode().ljust(128, b"\0")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fake_worker, args=(r, world, lib, uid, exchange, case_name, case_kw, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert sorted(res) == list(range(world))
+    assert max(res.values()) < 1e-10, res
