@@ -192,7 +192,9 @@ def main():
     gp = S.GridParameters(ring_uniform_L=L, storage=args.storage, **kw)
     mp = S.ModelParameters(ts=TS_OF.get(args.workload, TS), equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gp,
                            physical_params=dict(PAR))
-    impl = args.exchange_impl if (world > 1 and args.backend == "nccl") else "torch"
+    # the in-library exchange needs RCCL, i.e. one GPU per rank - or, for the one-GPU rehearsal of this very code path, the
+    # stand-in transport of the tests (SX_RCCL_LIB=tests/fake_rccl.cpp's .so) together with --backend gloo
+    impl = args.exchange_impl if (world > 1 and (args.backend == "nccl" or os.environ.get("SX_RCCL_LIB"))) else "torch"
     if args.exchange == "iface" and world > 1:
         # the interface-only solve needs 6 free spline coefficients per tile (up to 3 more cells where a rank-3 boundary condition
         # takes rows away): decided from the tile table, i.e. identically on every rank

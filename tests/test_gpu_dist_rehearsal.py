@@ -238,3 +238,26 @@ def test_in_library_exchange_multi_rank_through_a_stand_in_transport(tmp_path, e
     res = dict(q.get(timeout=5) for _ in range(world))
     assert sorted(res) == list(range(world))
     assert max(res.values()) < 1e-10, res
+
+
+@pytest.mark.gpu
+def test_bench_cli_two_ranks_in_library_exchange_through_the_stand_in_transport(tmp_path):
+    """bench.py's N = 2 path as the driver starts it (no launcher), with the exchange INSIDE the library: the probe / agree /
+    unique-id broadcast of LibExchange, the sequential self-check against the torch.distributed exchange and the timed loop -
+    on the one GPU, with tests/fake_rccl.cpp standing in for RCCL and gloo for torch's side."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = str(tmp_path / "libfake_rccl.so")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-o", lib, os.path.join(root, "tests", "fake_rccl.cpp"), "-lrt"],
+                   check=True, capture_output=True)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SX_RCCL_LIB"] = lib
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "rlz_small",
+           "--backend", "gloo", "--one-device", "--exchange-impl", "lib"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange_impl"] == "lib" and d["config"]["exchange"] == "iface"
+    assert d["config"]["exchange_selfcheck_max_rel_diff"] < 1e-12
