@@ -261,3 +261,32 @@ def test_bench_cli_two_ranks_in_library_exchange_through_the_stand_in_transport(
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange_impl"] == "lib" and d["config"]["exchange"] == "iface"
     assert d["config"]["exchange_selfcheck_max_rel_diff"] < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_exchange_set_up_rejects_bad_tile_tables_in_every_mode(mode):
+    """The tile table is validated before any offset table or buffer is built, whatever the protocol (a gap, an overlap or a
+    tile of fewer than 3 cells used to reach the halo / gather offset arithmetic of mode 1 unchecked), a failed set-up leaves
+    no exchange state behind, and sx_exchange without a communicator says so."""
+    import ctypes as C
+    import scythe_jl_amd as S
+    from scythe_jl_amd import _lib as L
+    case = cases.rl_slab(num_cells=24)
+    gp, mp_ = cases.hip_params(case)
+    lib = L.load()
+    tiles = [S.Grid(gp, mp_, c0, n, t + 2) for t, (c0, n) in enumerate([(0, 12), (12, 12)])]
+    hs = (C.c_void_p * 2)(*[g._h for g in tiles])
+    arr = lambda v: (C.c_int32 * 2)(*v)
+    try:
+        for cell0, ncells, msg in (([0, 13], [12, 11], "contiguous"), ([0, 12], [12, 11], "cover the patch"), ([0, 11], [11, 13], "match this handle")):
+            assert lib.sx_comm_init_local(hs, 2, arr(cell0), arr(ncells), mode) != 0
+            assert msg in lib.sx_last_error().decode(), lib.sx_last_error()
+        assert lib.sx_exchange_local(hs, 2) != 0 and b"sx_comm_init_local first" in lib.sx_last_error()
+        assert lib.sx_comm_prepare(tiles[0]._h, 2, 0, arr([0, 12]), arr([12, 12]), mode) == 0       # non-collective part alone
+        assert lib.sx_exchange(tiles[0]._h) != 0 and b"no communicator" in lib.sx_last_error()
+        assert lib.sx_comm_init_local(hs, 2, arr([0, 12]), arr([12, 12]), mode) == 0                 # and a good table still works
+        assert lib.sx_exchange_local(hs, 2) == 0
+    finally:
+        for g in tiles:
+            g.close()
