@@ -378,6 +378,32 @@ def main():
         }
         if native is not None:
             out["native_equivalent"] = native
+        if world == 1 and args.workload == "rlz_513x256x64" and not args.no_native and not nan:
+            # NOT the headline: the same model with SX_DEFER_DIAG=1 - the diagnostic variable w (written by the equation set
+            # before it is read, so its spline coefficients are consumed by output only) skips the forward transform and the
+            # solve inside the step and is brought up to date when something reads A or B; every observable is bit-identical
+            # (tests/test_gpu_parity.py::test_deferred_diagnostic_*).  The reference transforms all six variables every step,
+            # and so does the headline number above.
+            try:
+                os.environ["SX_DEFER_DIAG"] = "1"
+                rund = S.ModelRun(mp, num_tiles=1, device=dev)
+                del os.environ["SX_DEFER_DIAG"]
+                rund.set_initial_conditions([initial_condition(S.getGridpoints(rund.tiles[0]))])
+                for _ in range(20):
+                    rund.step()
+                torch.cuda.synchronize()
+                nd = max(20, min(args.steps, 100))
+                t1 = time.perf_counter()
+                for _ in range(nd):
+                    rund.step()
+                torch.cuda.synchronize()
+                dtd = (time.perf_counter() - t1) / nd
+                out["deferred_diagnostic"] = {"steps_per_s": 1.0 / dtd, "ms_per_step": 1e3 * dtd, "steps": nd, "nan": bool(rund.tiles[0].check_nan()),
+                                              "note": "opt-in (SX_DEFER_DIAG=1), not the headline: w's forward transform and solve on demand"}
+                rund.close()
+            except Exception as e:
+                os.environ.pop("SX_DEFER_DIAG", None)
+                out["deferred_diagnostic"] = {"steps_per_s": None, "error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_cells, args.cpu_steps)

@@ -617,6 +617,11 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
             FAIL();
         }
     }
+    h->v_lo = 0; h->v_cnt = h->V;
+    // deferred diagnostic variable (sx_internal.hpp): one-tile HRBL runs whose forward path is the FFT + matrix-core kernels
+    h->defer_diag = getenv("SX_DEFER_DIAG") && atoi(getenv("SX_DEFER_DIAG")) != 0 && h->eq == SX_EQ_ONEWAY_SW_HRBL && h->V == 6 &&
+                    h->ncells == h->nc && fft_path_ok(h) && h->has_z && (h->nz == 32 || h->nz == 64 || h->nz == 128) && h->sbw_mfma &&
+                    (h->nz <= 64 ? h->Zb <= 64 : h->Zb <= 96);
     if (sx_bind_patch_b(h, nullptr, nullptr)) FAIL();
     *out = h;
     return status();
@@ -758,6 +763,7 @@ int sx_state_size(const sx_handle *h, int64_t *n_doubles) {
 int sx_get_state(sx_handle *h, double *out) {
     clear_error();
     if (!h || !out) { set_error("null argument"); return 1; }
+    flush_diag(h);
     const size_t na = (size_t)h->nbt * h->C, nv = (size_t)h->V * h->N;
     out[0] = SX_STATE_MAGIC; out[1] = (double)na; out[2] = (double)nv; out[3] = h->semi ? 1.0 : 0.0;
     double *p = out + 4;
@@ -775,6 +781,7 @@ int sx_get_state(sx_handle *h, double *out) {
 
 int sx_set_state(sx_handle *h, const double *in) {
     clear_error();
+    if (h) h->diag_dirty = false;          // the blob carries every variable's coefficients
     if (!h || !in) { set_error("null argument"); return 1; }
     const size_t na = (size_t)h->nbt * h->C, nv = (size_t)h->V * h->N;
     if (in[0] != SX_STATE_MAGIC || in[1] != (double)na || in[2] != (double)nv || in[3] != (h->semi ? 1.0 : 0.0)) {
@@ -797,6 +804,7 @@ int sx_set_state(sx_handle *h, const double *in) {
 int sx_get_tile_spectral(sx_handle *h, double *out) {
     clear_error();
     if (!h || !out) { set_error("null argument"); return 1; }
+    flush_diag(h);
     std::vector<double> tmp((size_t)h->nbt * h->C);
     HIPOK(hipMemcpyAsync(tmp.data(), h->d_Btile, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, h->stream));
     HIPOK(hipStreamSynchronize(h->stream));
@@ -824,12 +832,14 @@ static int patch_to_device(sx_handle *h, const double *src, double *dst) {
 
 int sx_set_patch_spectral_b(sx_handle *h, const double *shared) {
     clear_error();
+    if (h) h->diag_dirty = false;
     if (!h || !shared) { set_error("null argument"); return 1; }
     return patch_to_device(h, shared, h->d_Bfull);
 }
 
 int sx_set_patch_spectral_a(sx_handle *h, const double *a) {
     clear_error();
+    if (h) h->diag_dirty = false;
     if (!h || !a) { set_error("null argument"); return 1; }
     return patch_to_device(h, a, h->d_A);
 }
@@ -837,6 +847,7 @@ int sx_set_patch_spectral_a(sx_handle *h, const double *a) {
 int sx_get_patch_spectral_a(sx_handle *h, double *out) {
     clear_error();
     if (!h || !out) { set_error("null argument"); return 1; }
+    flush_diag(h);
     std::vector<double> tmp((size_t)h->b_rDim * h->C);
     HIPOK(hipMemcpyAsync(tmp.data(), h->d_A, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, h->stream));
     HIPOK(hipStreamSynchronize(h->stream));
@@ -891,9 +902,28 @@ int sx_index_maps(const sx_handle *h, int64_t *patch_owned, int64_t *tile_owned,
     return 0;
 }
 
+}  // extern "C"
+
+namespace sx {
+// SX_DEFER_DIAG: bring the diagnostic variable's B and A coefficients up to date (forward transform of var_np1[w], radial +
+// vertical inner products, banded solve, for that one variable) - called by everything that lets A or B be observed
+void flush_diag(sx_handle *h) {
+    if (!h->diag_dirty) return;
+    h->diag_dirty = false;
+    h->v_lo = h->V - 1; h->v_cnt = 1;
+    launch_fl_forward(h);
+    launch_sb(h);
+    launch_solve(h);
+    h->v_lo = 0; h->v_cnt = h->V;
+}
+}  // namespace sx
+
+extern "C" {
+
 int sx_spectral_transform(sx_handle *h) {
     clear_error();
     if (!h) { set_error("null handle"); return 1; }
+    h->diag_dirty = false;             // every variable is transformed here
     launch_fl_forward(h);
     launch_sb(h);
     return status();
@@ -902,13 +932,16 @@ int sx_spectral_transform(sx_handle *h) {
 int sx_spline_transform(sx_handle *h) {
     clear_error();
     if (!h) { set_error("null handle"); return 1; }
+    if (h->diag_dirty) h->v_cnt = h->V - 1;      // after a deferred sx_advance: the prognostic variables only
     launch_solve(h);
+    h->v_cnt = h->V;
     return status();
 }
 
 int sx_tile_transform(sx_handle *h) {
     clear_error();
     if (!h) { set_error("null handle"); return 1; }
+    flush_diag(h);
     launch_zinv(h, true);
     launch_rl_inverse(h, true);
     return status();
@@ -928,8 +961,10 @@ int sx_advance(sx_handle *h, int32_t t) {
     if (t < 1) { set_error("t is 1-based"); return 1; }
     launch_zinv(h, false);
     launch_inverse_and_physics(h, t);
+    if (h->defer_diag) { h->v_cnt = h->V - 1; h->diag_dirty = true; }      // w's coefficients follow on demand (flush_diag)
     launch_fl_forward(h);
     launch_sb(h);
+    h->v_cnt = h->V;
     return status();
 }
 
@@ -960,6 +995,7 @@ int sx_max_abs(sx_handle *h, double *out) {
 int sx_tile_b_device(sx_handle *h, void **p, int64_t *rows, int64_t *cols) {
     clear_error();
     if (!h || !p) { set_error("null argument"); return 1; }
+    flush_diag(h);
     *p = h->d_Btile;
     if (rows) *rows = h->nbt;
     if (cols) *cols = h->C;
@@ -998,6 +1034,7 @@ int sx_bind_patch_b(sx_handle *h, const void *base, const int64_t *rowoff) {
 int sx_patch_a_device(sx_handle *h, void **p, int64_t *rows, int64_t *cols) {
     clear_error();
     if (!h || !p) { set_error("null argument"); return 1; }
+    flush_diag(h);
     *p = h->d_A;
     if (rows) *rows = h->b_rDim;
     if (cols) *cols = h->C;

@@ -606,10 +606,12 @@ template <int LOGL>
 static void launch_fwd(sx_handle *h, dim3 g) {
     const int L = 1 << LOGL;
     if (h->sp32)
-        hipLaunchKernelGGL((k_fl_forward_fft<LOGL, float>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, h->d_np1, reinterpret_cast<float *>(h->d_Fl),
+        hipLaunchKernelGGL((k_fl_forward_fft<LOGL, float>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, h->d_np1 + (int64_t)h->v_lo * h->N,
+                           reinterpret_cast<float *>(h->d_Fl) + (int64_t)h->v_lo * h->nz * h->K2,
                            h->d_kmax, h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N);
-    else
-        hipLaunchKernelGGL((k_fl_forward_fft<LOGL, double>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, h->d_np1, h->d_Fl, h->d_kmax,
+    else       // the variable window [v_lo, v_lo + v_cnt) (sx_internal.hpp): blockIdx.y counts from v_lo through the base pointers
+        hipLaunchKernelGGL((k_fl_forward_fft<LOGL, double>), g, dim3(fft_threads(L)), fft_lds(L), h->stream, h->d_np1 + (int64_t)h->v_lo * h->N,
+                           h->d_Fl + (int64_t)h->v_lo * h->nz * h->K2, h->d_kmax,
                            h->d_pstart, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->K2, h->N);
 }
 
@@ -657,7 +659,7 @@ void launch_fl_forward_fft(sx_handle *h) {
     const int id = timer_id(h, "k_fl_forward");
     timer_begin(h, id);
     const int fzc = fft_fzc(h->uniform_L);
-    dim3 g((h->nz + fzc - 1) / fzc, h->V, h->nrings);
+    dim3 g((h->nz + fzc - 1) / fzc, h->v_cnt, h->nrings);
     switch (ilog2(h->uniform_L)) {
         case 4: launch_fwd<4>(h, g); break;
         case 5: launch_fwd<5>(h, g); break;

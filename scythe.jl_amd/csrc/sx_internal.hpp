@@ -122,6 +122,12 @@ struct sx_handle {
     int n_dft_items[3] = {0, 0, 0};
     int n_dft_big[3] = {0, 0, 0};            // of which (listed first) rings with kmax > DFT_KMAX_SINGLE: chunked kernels
     int dft_lcap_small = 0, dft_kcap_small = 0;   // largest ring length / kmax among the other rings
+    // SX_DEFER_DIAG=1 (one-tile HRBL runs on the FFT path): the diagnostic variable w is written by the equation set before it is
+    // read (src/shallowWaterModels.jl:69, 430), so its spline coefficients are consumed by OUTPUT only; sx_advance then sends
+    // the five prognostic variables through the forward transform and the solve, and w's follow on demand (flush_diag) when
+    // something reads A or B.  v_lo / v_cnt: the variable window the forward-path launchers cover.
+    int defer_diag = 0, v_lo = 0, v_cnt = 0;
+    bool diag_dirty = false;
     int fuse_zinv = 0;      // SX_FUSE_ZINV=1: vertical inverse inside the node FFT kernel (measured slower: sx_fft.hip)
     int sbw_mfma = 1;       // k_sbw_mfma (matrix-core vertical contraction, operator in registers) for zDim 64 / 32 (SX_SBW_MFMA=0: k_sbw)
     int sbw_prefetch = 0;   // k_sbw requests the next cell's ring spectra before contracting the current node (SX_SBW_PF=0: off)
@@ -207,6 +213,7 @@ void set_error(const std::string &msg);
 void clear_error();
 int error_status();   // 1 if set_error has been called since the last clear_error
 void comm_release(sx_handle *h);
+void flush_diag(sx_handle *h);
 void iface_release(sx_handle *h);
 bool tile_table_ok(const sx_handle *h, int n, int me, const int32_t *cell0, const int32_t *ncells);
 #ifdef SX_PHASES

@@ -2004,14 +2004,15 @@ void launch_sb(sx_handle *h) {
             static const bool t256_env = !(getenv("SX_SBW_T256") && atoi(getenv("SX_SBW_T256")) == 0);
             const bool t256 = t256_env && mf && h->nz == 64;
             const int bw = ((mf && h->nz == 128) || t256) ? 32 : 64;         // wavenumber blocks per workgroup
-            const int groups = ((h->K2 + bw - 1) / bw) * h->V;
+            const int groups = ((h->K2 + bw - 1) / bw) * h->v_cnt;
             const bool pf = (h->sbw_prefetch && h->nz <= 64) || mf;
             static const int seg_env = getenv("SX_SBW_SEG") ? atoi(getenv("SX_SBW_SEG")) : 0;      // experiments: segments per (block group, variable)
             const int nseg = seg_env > 0 ? seg_env : std::max(1, ((mf && h->nz == 128) || t256 ? 512 : pf || h->nz == 128 ? 256 : 384) / groups);
             // small tiles (multi-GPU strong scaling): the kernel is then one workgroup's latency chain, which is proportional
             // to the cells it walks, so short segments (down to 2 cells + 3 warm-up) beat the saved re-reads
             const int cps = std::max(h->ncells <= 64 ? 2 : 6, (h->ncells + nseg - 1) / nseg);
-            dim3 gw((h->K2 + bw - 1) / bw, h->V, (h->ncells + cps - 1) / cps);
+            dim3 gw((h->K2 + bw - 1) / bw, h->v_cnt, (h->ncells + cps - 1) / cps);      // variable window: see sx_internal.hpp
+            const int64_t flo = (int64_t)h->v_lo * h->nz * h->K2, blo = (int64_t)h->v_lo * h->Zb * h->K2;
 #ifdef SX_PHASES
             if (!g_sbw_buf) {
                 g_sbw_n = (int64_t)gw.x * gw.y * gw.z;
@@ -2026,10 +2027,10 @@ void launch_sb(sx_handle *h) {
             if (h->sp32) {             // fp32-stored ring spectra (storage_f32 = 2; sx_create guarantees the matrix-core kernel applies)
                 auto kf = t256 ? k_sbw_mfma<64, 32, 256, float> : h->nz == 64 ? k_sbw_mfma<64, 64, 512, float>
                           : h->nz == 32 ? k_sbw_mfma<32, 64, 512, float> : k_sbw_mfma<128, 32, 512, float>;
-                hipLaunchKernelGGL(kf, gw, dim3(t256 ? 256 : 512), 0, h->stream, reinterpret_cast<const float *>(h->d_Fl), h->d_Btile, h->d_phi,
+                hipLaunchKernelGGL(kf, gw, dim3(t256 ? 256 : 512), 0, h->stream, reinterpret_cast<const float *>(h->d_Fl) + flo, h->d_Btile + blo, h->d_phi,
                                    h->d_wq, h->d_CB, h->ncells, h->V, h->Zb, h->K2, h->C, cps);
             } else
-            hipLaunchKernelGGL(kern, gw, dim3(t256 ? 256 : 512), 0, h->stream, h->d_Fl, h->d_Btile, h->d_phi, h->d_wq, h->d_CB, h->ncells,
+            hipLaunchKernelGGL(kern, gw, dim3(t256 ? 256 : 512), 0, h->stream, h->d_Fl + flo, h->d_Btile + blo, h->d_phi, h->d_wq, h->d_CB, h->ncells,
                                h->V, h->Zb, h->K2, h->C, cps);
             HIPCHK(hipGetLastError());
             timer_end(h);
@@ -2056,10 +2057,13 @@ void launch_solve(sx_handle *h) {
     const int id = timer_id(h, "k_solve");
     timer_begin(h, id);
     dim3 g((h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1, h->V * h->Zb);
-    if (h->d_Bsrc == h->d_Bfull)     // internal contiguous B: no offset tables needed
-        hipLaunchKernelGGL(k_solve<true>, g, dim3(64), sizeof(double) * 4 * h->b_rDim, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff, h->d_neg1,
-                           h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2, 0,
+    if (h->d_Bsrc == h->d_Bfull) {   // internal contiguous B: no offset tables needed; the variable window through the base pointers
+        const int64_t clo = (int64_t)h->v_lo * h->Zb * h->K2;
+        g.y = h->v_cnt * h->Zb;
+        hipLaunchKernelGGL(k_solve<true>, g, dim3(64), sizeof(double) * 4 * h->b_rDim, h->stream, h->d_Bsrc + clo, h->d_rowoff, h->d_neg1, h->d_A + clo, h->d_aoff, h->d_neg1,
+                           h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb, h->K2, h->v_lo * h->Zb,
                            h->C);
+    }
     else
         hipLaunchKernelGGL(k_solve<false>, g, dim3(64), sizeof(double) * 8 * h->b_rDim, h->stream, h->d_Bsrc, h->d_rowoff, h->d_neg1, h->d_A, h->d_aoff,
                            h->d_neg1, h->d_cls, h->d_cmeta, h->d_gl, h->d_gr, h->d_Lband, h->d_Ldinv, h->d_Larrow, h->b_rDim, h->Zb,

@@ -115,6 +115,28 @@ def test_vertical_inverse_fused_into_the_node_fft_gives_the_same_fields(monkeypa
         assert _run(cases.rlz_hrbl(**kw), 3) < TOL
 
 
+@pytest.mark.parametrize("kw", [{"num_cells": 8, "zDim": 32, "ring_L": 32}, {"num_cells": 6, "zDim": 64, "ring_L": 256}])
+def test_deferred_diagnostic_variable_is_bit_identical_where_it_can_be_observed(monkeypatch, kw):
+    """SX_DEFER_DIAG=1 (opt-in): the diagnostic w of the HRBL set is written before it is read (src/shallowWaterModels.jl:69, 430),
+    so its spline coefficients are consumed by output only; sx_advance then sends the five prognostic variables through the
+    forward transform and the solve and w's follow when something reads A or B.  Every observable - physical (all slots, w
+    included), the A coefficients, the restart blob - is BIT-identical to the run that transforms all six every step."""
+    case = cases.rlz_hrbl(**kw)
+    ref = cases.HipModel(case)
+    monkeypatch.setenv("SX_DEFER_DIAG", "1")
+    dfr = cases.HipModel(case)
+    for _ in range(5):
+        ref.step()
+        dfr.step()
+    assert np.array_equal(dfr.A, ref.A)
+    assert np.array_equal(dfr.physical(), ref.physical())
+    for _ in range(3):
+        ref.step()
+        dfr.step()
+    assert np.array_equal(dfr.run.tiles[0].get_state(), ref.run.tiles[0].get_state())
+    assert np.array_equal(dfr.physical(), ref.physical())
+
+
 def test_rlz_hrbl_native_rings_on_the_matrix_core_dft():
     """Native ragged rings with >= 8 levels take the f64-MFMA truncated-DFT kernels (sx_dft.hip): 90 rings of 8..364
     points, four launch classes, partial level chunk (zDim 20)."""
