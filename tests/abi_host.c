@@ -30,8 +30,70 @@
 #define OK(call) \
     do { if ((call) != 0) { fprintf(stderr, "%s failed: %s\n", #call, p_sx_last_error()); return 1; } } while (0)
 
+/* abi_host case <libscythe_hip.so> <case.bin> <out.bin>: ANY grid / equation set, described by a small binary file the test
+ * writes (what the Julia glue's createHipModelTile fills in from GridParameters / ModelParameters):
+ *   int32  geometry, num_cells, nvars, zDim, ring_uniform_L, equation_set, semiimplicit, steps, w_index, xi_index, col_var
+ *   double xmin, xmax, zmin, zmax, ts, params[SX_NPARAMS]
+ *   int32  bcl[nvars], bcr[nvars], bcb[nvars], bct[nvars]
+ *   int64  n_points;  double values[n_points * nvars]      (column-major [point, var]: the initial condition)
+ * One tile; writes physical[n_points, nvars, n_derivs] after <steps> steps and sx_max_abs's nvars values behind it. */
+static int run_case(int argc, char **argv) {
+    if (argc != 5) { fprintf(stderr, "usage: abi_host case lib case.bin out.bin\n"); return 2; }
+    void *lib = dlopen(argv[2], RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+    BIND(sx_last_error) BIND(sx_create) BIND(sx_destroy) BIND(sx_get_dims) BIND(sx_set_physical_values) BIND(sx_spectral_transform)
+    BIND(sx_spline_transform) BIND(sx_advance) BIND(sx_tile_transform) BIND(sx_get_physical) BIND(sx_check_nan) BIND(sx_max_abs)
+    FILE *f = fopen(argv[3], "rb");
+    if (!f) { fprintf(stderr, "cannot read %s\n", argv[3]); return 1; }
+    int32_t hd[11];
+    double dd[5 + SX_NPARAMS];
+    if (fread(hd, sizeof(int32_t), 11, f) != 11 || fread(dd, sizeof(double), 5 + SX_NPARAMS, f) != 5 + SX_NPARAMS) return 1;
+    const int nv = hd[2];
+    int32_t *bc = malloc(sizeof(int32_t) * 4 * nv);
+    int64_t npts = 0;
+    if (fread(bc, sizeof(int32_t), 4 * nv, f) != (size_t)(4 * nv) || fread(&npts, sizeof(int64_t), 1, f) != 1) return 1;
+    double *vals = malloc(sizeof(double) * npts * nv);
+    if (fread(vals, sizeof(double), npts * nv, f) != (size_t)(npts * nv)) return 1;
+    fclose(f);
+    sx_grid_desc gd;
+    memset(&gd, 0, sizeof gd);
+    gd.abi_version = SX_ABI_VERSION; gd.geometry = hd[0]; gd.num_cells = hd[1]; gd.nvars = nv; gd.zDim = hd[3]; gd.ring_uniform_L = hd[4];
+    gd.xmin = dd[0]; gd.xmax = dd[1]; gd.zmin = dd[2]; gd.zmax = dd[3]; gd.l_q = 2.0;
+    gd.bcl = bc; gd.bcr = bc + nv; gd.bcb = bc + 2 * nv; gd.bct = bc + 3 * nv;
+    gd.tile_cell0 = 0; gd.tile_num_cells = hd[1]; gd.tile_num = 2;
+    sx_model_desc md;
+    memset(&md, 0, sizeof md);
+    md.ts = dd[4]; md.equation_set = hd[5]; md.semiimplicit = hd[6]; md.params = dd + 5;
+    md.w_index = hd[8]; md.xi_index = hd[9]; md.col_var = hd[10];
+    sx_handle *h = 0;
+    OK(p_sx_create(&gd, &md, &h));
+    sx_dims d;
+    OK(p_sx_get_dims(h, &d));
+    if (d.n_points != npts || d.n_vars != nv) { fprintf(stderr, "case file does not match the grid: %ld points\n", (long)d.n_points); return 1; }
+    OK(p_sx_set_physical_values(h, vals));
+    OK(p_sx_spectral_transform(h));
+    OK(p_sx_spline_transform(h));
+    for (int s = 1; s <= hd[7]; s++) { OK(p_sx_advance(h, s)); OK(p_sx_spline_transform(h)); }
+    int32_t flag = 0;
+    OK(p_sx_check_nan(h, &flag));
+    if (flag) { fprintf(stderr, "NaN in the model state\n"); return 1; }
+    double *mx = malloc(sizeof(double) * nv);
+    OK(p_sx_max_abs(h, mx));
+    OK(p_sx_tile_transform(h));
+    const size_t np = (size_t)npts * nv * d.n_derivs;
+    double *phys = malloc(sizeof(double) * np);
+    OK(p_sx_get_physical(h, phys));
+    f = fopen(argv[4], "wb");
+    if (!f || fwrite(phys, sizeof(double), np, f) != np || fwrite(mx, sizeof(double), nv, f) != (size_t)nv) { fprintf(stderr, "cannot write\n"); return 1; }
+    fclose(f);
+    OK(p_sx_destroy(h));
+    printf("abi_host case ok: %d steps, %ld points x %d vars x %d slots\n", hd[7], (long)npts, nv, d.n_derivs);
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    if (argc != 5) { fprintf(stderr, "usage: abi_host lib steps tiles out.bin\n"); return 2; }
+    if (argc >= 2 && strcmp(argv[1], "case") == 0) return run_case(argc, argv);
+    if (argc != 5) { fprintf(stderr, "usage: abi_host lib steps tiles out.bin | abi_host case lib case.bin out.bin\n"); return 2; }
     const int steps = atoi(argv[2]), ntiles = atoi(argv[3]);
     void *lib = dlopen(argv[1], RTLD_NOW | RTLD_GLOBAL);
     if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
