@@ -175,7 +175,8 @@ def test_tiles_on_one_gpu_match_single_patch_oracle(maker, kw, ntiles, exchange,
 
 @pytest.mark.parametrize("maker,kw,ntiles", [(cases.rlz_hrbl, {"num_cells": 24, "zDim": 32, "ring_L": 16}, 3),
                                              (cases.rlz_hrbl, {"num_cells": 20, "zDim": 10}, 2),            # native ragged rings
-                                             (cases.kat_r, {}, 2), (cases.kat_r, {}, 3), (cases.kat_r, {}, 8),   # PERIODIC: wrap-around rows
+                                             (cases.kat_r, {}, 2), (cases.kat_r, {}, 3), (cases.kat_r, {}, 8), (cases.kat_r, {}, 10),   # PERIODIC: wrap-around rows; 10 tiles: the 160-row reduced operator
+                                             (cases.r_bcs, {"bcl": "R1T0", "bcr": "R1T1", "num_cells": 128}, 16),
                                              (cases.rl_slab, {"num_cells": 20}, 2), (cases.rl_slab, {"num_cells": 30}, 3), (cases.rl_slab, {"num_cells": 31, "ring_L": 16}, 4),
                                              (cases.rl_slab, {"num_cells": 80, "ring_L": 16}, 2),            # 40 unknowns per tile: memory-resident local solve
                                              (cases.rz_semiimplicit, {"num_cells": 21}, 3),
