@@ -363,7 +363,11 @@ def main():
                                    "Oneway_ShallowWater_HeightResolvedBL, uniform ring table kmax<=%d, b_zDim %d"
                                    % (3 * nc, L, nz, L // 2 - 1, int(tile.dims.b_zDim)),
                        "num_cells": nc, "tiles": world, "tile_cells": list(run.layout.ncells), "exchange": run.exchange_kind,
-                       "exchange_impl": (impl if world > 1 else "none"), "exchange_selfcheck_max_rel_diff": selfcheck, "ts": TS_OF.get(args.workload, TS), "nan": bool(nan)},
+                       "exchange_impl": (impl if world > 1 else "none"), "exchange_selfcheck_max_rel_diff": selfcheck,
+                       # what ran on the device right before the W warm-up steps (from an idle GPU the first ~25 steps of
+                       # any run are up to 18 % slow)
+                       "device_busy_before_warmup": ("native_equivalent run" if native is not None else
+                                                     "self-check's torch.distributed run, 100 steps" if preheat is not None else "nothing (cold start)"), "ts": TS_OF.get(args.workload, TS), "nan": bool(nan)},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
