@@ -120,18 +120,45 @@ def cpu_baseline(workload, sample_cells, steps):
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher in front: start `torch.distributed.run` with N ranks of this very
     command line as a child process (never exec: this is called before torch or HIP are imported, and the parent never
-    touches the GPU), pass the ranks' stdout / stderr through and return the launcher's exit status."""
+    touches the GPU), pass the ranks' stdout / stderr through and return the launcher's exit status.
+    Watchdog: the in-library RCCL exchange has never run with more than one rank on real hardware (no multi-GPU node was
+    available to the builder).  If the job has not finished after SX_BENCH_TIMEOUT seconds (default 420) the launcher's own
+    process group - exactly the processes started here - is killed and the job is run ONCE more with the exchange done by
+    torch.distributed (`--exchange-impl torch`, recorded in config.exchange_impl); a second timeout is a failure."""
+    import signal
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("OMP_NUM_THREADS", "1")       # what the launcher would set anyway, without its warning
-    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+    def attempt(extra):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        env = dict(os.environ)
+        env.setdefault("OMP_NUM_THREADS", "1")       # what the launcher would set anyway, without its warning
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True)
+        try:
+            return proc.wait(timeout=float(os.environ.get("SX_BENCH_TIMEOUT", "420")))
+        except subprocess.TimeoutExpired:
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(proc.pid, sig)             # the session started above: the launcher and its ranks, nothing else
+                except ProcessLookupError:
+                    break
+                try:
+                    proc.wait(timeout=15)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
+            return None
+
+    rc = attempt([])
+    if rc is None and "--exchange-impl" not in sys.argv[1:]:
+        print("bench.py: the %d-rank job did not finish in time; once more with --exchange-impl torch" % n, file=sys.stderr, flush=True)
+        rc = attempt(["--exchange-impl", "torch"])
+    return 124 if rc is None else rc
 
 
 def main():
