@@ -320,7 +320,8 @@ class ModelRun:
                  split="reference", impl="torch", unique_id=None):
         """exchange: "a2a" = transposed solve over all-to-all, "iface" = interface-only solve (tile-local solves, all-to-all of
         10 rows per tile around a small reduced system: least traffic, shortest recurrence), "gather" = the reference's
-        protocol (halo chain + gather of owned rows + redundant patch solve on every tile).
+        protocol (halo chain + gather of owned rows + redundant patch solve on every tile), "auto" = "iface" where every tile
+        has at least 9 cells, else "a2a".
         impl (use_dist only): "lib" = RCCL calls inside libscythe_hip.so on the tile's stream (sx_exchange; also valid with
         ONE tile, where every send is a send to self - the one-GPU self-test of that code path), "torch" =
         torch.distributed collectives on device tensors (also what the gloo rehearsals use)."""
@@ -329,6 +330,8 @@ class ModelRun:
         self.patch = patch
         self.num_tiles = num_tiles
         self.layout = PatchLayout(patch, num_tiles, split=split)
+        if exchange == "auto":      # the interface-only solve where every tile is large enough for it (6 free coefficients: >= 9 cells
+            exchange = "iface" if num_tiles > 1 and min(self.layout.ncells) >= 9 else "a2a"          # covers every boundary condition)
         self.use_dist = use_dist
         if use_dist:
             t = rank
@@ -478,7 +481,7 @@ def integrate_model(model: ModelParameters, num_tiles=1, verbose=False):
     device = None
     if num_tiles > 1:
         device = "cuda"
-    run = ModelRun(model, num_tiles=num_tiles, device=device)
+    run = ModelRun(model, num_tiles=num_tiles, device=device, exchange="auto")
     print("Initializing with %d workers and tiles" % num_tiles, file=log)
     vals = read_physical_grid(model.initial_conditions, model.grid_params, run)
     run.set_initial_conditions(vals)
