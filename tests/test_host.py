@@ -226,3 +226,15 @@ def test_staged_interface_solve_equals_the_patch_solve():
                 got = ps.apply(t, y, out[t])
                 want = ref[cell0[t]:cell0[t] + cells[t] + 3]
                 assert np.abs(got - want).max() <= 1e-11 * np.abs(ref).max(), (bcl, bcr, cells, t)
+
+
+def test_exchange_auto_picks_the_interface_only_solve_where_tiles_allow_it():
+    """ModelRun(exchange="auto") / integrate_model: "iface" when every tile has >= 9 cells (6 free spline coefficients under any
+    boundary condition), else the transposed solve - decided from calcTileSizes alone, i.e. identically on every rank."""
+    import scythe_jl_amd as S
+    gp = lambda nc: S.GridParameters(geometry="R", xmin=0.0, xmax=1.0, num_cells=nc, vars={"u": 1})
+    pick = lambda nc, n: "iface" if n > 1 and min(S.PatchLayout(gp(nc), n).ncells) >= 9 else "a2a"
+    assert pick(100, 2) == "iface" and pick(171, 8) == "iface" and pick(24, 4) == "a2a" and pick(100, 1) == "a2a"
+    # native rings balance gridpoints: the outer tiles are the short ones
+    lay = S.PatchLayout(S.GridParameters(geometry="RL", xmin=0.0, xmax=1.0, num_cells=171, vars={"u": 1}), 8)
+    assert sum(lay.ncells) == 171 and min(lay.ncells) >= 9
