@@ -158,6 +158,38 @@ def test_rlz_advection():
     assert _run(cases.rlz_advection(), 6) < TOL
 
 
+@pytest.mark.parametrize("maker,kw,steps", [
+    (cases.rlz_advection, {"num_cells": 3, "zDim": 4}, 4),                      # the smallest legal grid: 3 cells, 4 Chebyshev levels
+    (cases.rlz_advection, {"num_cells": 3, "zDim": 4, "ring_L": 16}, 4),        # ... on the shortest power-of-two ring table
+    (cases.rz_advection, {"num_cells": 3, "zDim": 5}, 4),
+    (cases.rl_advection, {"num_cells": 3}, 4),
+    (cases.rlz_hrbl, {"num_cells": 3, "zDim": 16, "ring_L": 16}, 2),           # one 16-level chunk, every ring on the ring-wise path (kDim 7 < rings 9)
+    (cases.rlz_advection, {"num_cells": 4, "zDim": 200}, 2),                    # 200 levels: the non-matrix-core column kernels
+    (cases.r_bcs, {"bcl": "R3", "bcr": "R3", "num_cells": 7}, 4),               # 10 nodes, 6 of them fixed: four free coefficients, the fewest a spline class takes
+])
+def test_edge_shapes(maker, kw, steps):
+    """Smallest and largest shapes the ABI accepts: 3 cells (calcTileSizes' minimum), 4 levels (sx_create's minimum), one
+    16-level chunk, 200 levels, a spline with four free coefficients.  At 200 levels the Chebyshev d2/dz2 slot of two correct
+    fp64 evaluations differs by N^4 eps = 3.5e-7 of its scale: the values are held to 1e-10 there, the slots to 1e-6."""
+    case = maker(**kw)
+    if kw.get("zDim", 0) < 100:
+        assert _run(case, steps) < TOL
+        return
+    hip, orc = cases.HipModel(case), cases.OracleModel(case)
+    for _ in range(steps):
+        hip.step()
+        orc.step()
+    a, b = hip.physical(), orc.physical()
+    assert cases.rel_err_per_var(a[:, :, :1], b[:, :, :1]) < TOL
+    assert cases.rel_err_per_var(a, b) < 1e-6
+
+
+def test_too_few_cells_for_the_boundary_conditions_is_refused():
+    import scythe_jl_amd as S
+    with pytest.raises(S.ScytheHipError, match="too few cells"):
+        cases.HipModel(cases.r_bcs(bcl="R3", bcr="R3", num_cells=4))
+
+
 @pytest.mark.parametrize("maker,kw,ntiles", [(cases.rlz_hrbl, {"num_cells": 9, "zDim": 32, "ring_L": 16}, 3),
                                              (cases.kat_r, {}, 2), (cases.kat_r, {}, 3), (cases.rl_slab, {"num_cells": 9}, 2),
                                              (cases.rl_slab, {"num_cells": 10}, 3), (cases.rlz_hrbl, {"num_cells": 7}, 2),
