@@ -267,3 +267,39 @@ def test_c_oracle_builds_its_own_operators_and_they_match_the_numpy_definition()
     assert OC.lib().orc_ops_helmholtz(gz.zmin, gz.zmax, 24, 1.2e5, 2.5, OC._pd(W), OC._pd(X)) == 0
     Wn, Xn = O.semi_matrices(gz.cheb("w"), 1.2e5, 2.5)
     assert rel(W, Wn) < 1e-13 and rel(X, Xn) < 1e-13
+
+
+@pytest.mark.parametrize("geometry,ring_L", [("RLZ", 32), ("RL", None), ("RZ", None)])
+def test_oracle_reproduces_the_closed_form_derivatives_of_an_analytic_field(geometry, ring_L):
+    """The oracle against mathematics (tests/test_gpu_analytic.py does the same with the HIP path): forward transform, spline
+    solve and inverse transform of u = F(r) A(lambda) G(z); every derivative slot within the cubic spline's truncation error of
+    the closed form, falling at the spline's rate (16 / 8 / 4 per halving of DX) - no convention error survives that."""
+    from tests import test_gpu_analytic as T
+
+    def errors(nc):
+        nv = {"RLZ": {"h": 1, "u": 2, "v": 3}, "RL": {"h": 1, "u": 2, "v": 3}, "RZ": {"h": 1, "u": 2, "v": 3, "w": 4}}[geometry]
+        grid = dict(geometry=geometry, xmin=0.0, xmax=16.0, num_cells=nc, vars=nv)
+        if "Z" in geometry:
+            grid.update(zmin=0.0, zmax=T.ZMAX, zDim=24)
+        if "L" in geometry:
+            grid.update(ring_L=ring_L)
+        keep = {}
+
+        def ic(p):
+            r = p[:, 0]
+            e = T.field(r, p[:, 1] if "L" in geometry else 0 * r, p[:, -1] if "Z" in geometry else 0 * r + 1.0)
+            keep["exact"] = e
+            v = np.zeros((len(r), len(nv)))
+            v[:, 0] = e[:, 0]
+            return v
+        eq = {"RLZ": "LinearAdvectionRLZ", "RL": "LinearAdvectionRL", "RZ": "LinearAdvectionRZ"}[geometry]
+        ph = cases.OracleModel(dict(name="analytic", grid=grid, eq=eq, ts=0.01, par=dict(K=0.0), ic=ic)).physical()
+        slots = {"RLZ": [0, 1, 2, 3, 4, 5, 6], "RL": [0, 1, 2, 3, 4], "RZ": [0, 1, 2, 5, 6]}[geometry]
+        ex = keep["exact"]
+        return slots, [np.abs(ph[:, 0, d] - ex[:, s]).max() / np.abs(ex[:, s]).max() for d, s in enumerate(slots)]
+
+    slots, e64 = errors(64)
+    _, e128 = errors(128)
+    for s, a, b in zip(slots, e64, e128):
+        assert a < T.BOUND[s], (T.NAMES[s], a)
+        assert a / b > {1: 5.0, 2: 3.0}.get(s, 10.0), (T.NAMES[s], a, b)
