@@ -303,3 +303,14 @@ def test_oracle_reproduces_the_closed_form_derivatives_of_an_analytic_field(geom
     for s, a, b in zip(slots, e64, e128):
         assert a < T.BOUND[s], (T.NAMES[s], a)
         assert a / b > {1: 5.0, 2: 3.0}.get(s, 10.0), (T.NAMES[s], a, b)
+
+
+def test_oracle_semiimplicit_standing_acoustic_wave_is_second_order_to_the_closed_form():
+    """tests/test_gpu_analytic.py's standing-wave check on the oracle (C port and the numpy twin with the reference's LU)."""
+    from tests import test_gpu_analytic as T
+    import functools
+    for cls in (cases.OracleModel, functools.partial(cases.OracleModel, numpy_twin=True, helmholtz="lu")):
+        a = T.standing_wave_errors(cls, 0.5, 40)
+        b = T.standing_wave_errors(cls, 0.25, 80)
+        assert a[0] < 6e-3 and a[1] < 4e-3
+        assert 3.5 < a[0] / b[0] < 4.5 and 3.5 < a[1] / b[1] < 4.5
