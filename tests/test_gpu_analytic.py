@@ -214,3 +214,42 @@ def test_semiimplicit_standing_acoustic_wave_converges_to_the_closed_form():
     print("\nstanding wave: ts 0.5 xi %.2e w %.2e   ts 0.25 xi %.2e w %.2e" % (a + b))
     assert a[0] < 6e-3 and a[1] < 4e-3
     assert 3.5 < a[0] / b[0] < 4.5 and 3.5 < a[1] / b[1] < 4.5
+
+
+def balanced_vortex_drift(model_cls, maker, kw, steps=50):
+    """A vortex in gradient-wind balance, g dh/dr = vg (f + vg / r) with vg = V0 (r/R) exp(-r^2 / 2R^2) and h in closed form, is
+    a steady state of the free-atmosphere part (h, ug, vg) of the shallow-water sets (src/shallowWaterModels.jl:72-108,
+    433-447); the boundary layer beneath it (ub, vb) spins up, which shows that the run is doing something."""
+    g, f, R, V0 = 9.81, 5.0e-5, 5.0e4, 30.0
+
+    def ic(p):
+        r = p[:, 0]
+        vg = V0 * (r / R) * np.exp(-0.5 * (r / R) ** 2)
+        h = -(0.5 * V0 * V0 * np.exp(-(r / R) ** 2) + f * V0 * R * np.exp(-0.5 * (r / R) ** 2)) / g
+        return np.stack([h, 0 * r, vg, 0 * r, 0.5 * vg, 0 * r], axis=1)
+    case = maker(**kw)
+    case["ic"] = ic
+    m = model_cls(case)
+    p0 = m.physical().copy()
+    for _ in range(steps):
+        m.step()
+    p = m.physical()
+    if hasattr(m, "run"):
+        m.run.close()
+    return (np.abs(p[:, 1, 0]).max(), np.abs(p[:, 0, 0] - p0[:, 0, 0]).max() / np.abs(p0[:, 0, 0]).max(),
+            np.abs(p[:, 2, 0] - p0[:, 2, 0]).max() / V0, np.abs(p[:, 3, 0]).max())
+
+
+@pytest.mark.parametrize("set_name", ["rl_slab", "rlz_hrbl"])
+def test_gradient_wind_balanced_vortex_is_a_steady_state(set_name):
+    """50 steps of 3 s: an unbalanced pressure-gradient, Coriolis or centrifugal term (a sign, a missing 1/r, g or f) would
+    accelerate ug to 7.5 m/s; balanced, it stays at 2.3e-4 m/s with 48 cells and 9e-6 with 96 (truncation), h and vg within
+    2e-4 / 6e-4 of their initial fields (the per-step spline filter), while the boundary-layer inflow reaches 0.9 m/s."""
+    from tests import cases
+    maker = getattr(cases, set_name)
+    extra = {"zDim": 10} if set_name == "rlz_hrbl" else {}
+    a = balanced_vortex_drift(cases.HipModel, maker, dict(num_cells=48, ring_L=16, **extra))
+    b = balanced_vortex_drift(cases.HipModel, maker, dict(num_cells=96, ring_L=16, **extra))
+    print("\n%s: 48 cells ug %.2e dh %.2e dvg %.2e ub %.2f   96 cells ug %.2e dh %.2e dvg %.2e" % ((set_name,) + a + b[:3]))
+    assert a[0] < 5e-4 and a[1] < 4e-4 and a[2] < 1e-3 and a[3] > 0.5
+    assert a[0] / b[0] > 8.0 and b[1] < a[1] and b[2] < a[2]
