@@ -124,7 +124,8 @@ def spawn_ranks(n):
     Watchdog: the in-library RCCL exchange has never run with more than one rank on real hardware (no multi-GPU node was
     available to the builder).  If the job has not finished after SX_BENCH_TIMEOUT seconds (default 420) the launcher's own
     process group - exactly the processes started here - is killed and the job is run ONCE more with the exchange done by
-    torch.distributed (`--exchange-impl torch`, recorded in config.exchange_impl); a second timeout is a failure."""
+    torch.distributed (`--exchange-impl torch`, recorded in config.exchange_impl); the same happens if the job exits with a
+    non-zero status (its output has already gone to stderr).  A second failure is the failure."""
     import signal
     import socket
     import subprocess
@@ -155,8 +156,9 @@ def spawn_ranks(n):
             return None
 
     rc = attempt([])
-    if rc is None and "--exchange-impl" not in sys.argv[1:]:
-        print("bench.py: the %d-rank job did not finish in time; once more with --exchange-impl torch" % n, file=sys.stderr, flush=True)
+    if rc != 0 and "--exchange-impl" not in sys.argv[1:]:
+        print("bench.py: the %d-rank job %s; once more with --exchange-impl torch" % (n, "did not finish in time" if rc is None else "exited with status %d" % rc),
+              file=sys.stderr, flush=True)
         rc = attempt(["--exchange-impl", "torch"])
     return 124 if rc is None else rc
 
