@@ -344,16 +344,18 @@ int sx_exchange(sx_handle *h) {
         const bool ifc = c->mode == 2;
         if (ifc ? sx_iface_local(h, c->tile_buf) : sx_a2a_pack_b(h, c->tile_buf)) return 1;
         NCCLOK(grp.start());
+        // a rank that owns no column (more ranks than columns to share out) exchanges nothing: its counts are zero on BOTH
+        // sides of the pair (rows x columns of the owner), so sender and receiver skip the same messages
         for (int d = 0; d < n; d++) {
-            NCCLOK(R->Send(c->tile_buf + c->tile_off[d], (size_t)c->tile_cnt[d], NCCL_DOUBLE, d, c->comm, s));
-            NCCLOK(R->Recv(c->own_in + c->own_off[d], (size_t)c->own_cnt[d], NCCL_DOUBLE, d, c->comm, s));
+            if (c->tile_cnt[d]) NCCLOK(R->Send(c->tile_buf + c->tile_off[d], (size_t)c->tile_cnt[d], NCCL_DOUBLE, d, c->comm, s));
+            if (c->own_cnt[d]) NCCLOK(R->Recv(c->own_in + c->own_off[d], (size_t)c->own_cnt[d], NCCL_DOUBLE, d, c->comm, s));
         }
         NCCLOK(grp.end());
         if (ifc ? sx_iface_reduce(h, c->own_in, c->own_out) : sx_a2a_solve(h, c->own_in, c->own_out)) return 1;
         NCCLOK(grp.start());
         for (int t = 0; t < n; t++) {
-            NCCLOK(R->Send(c->own_out + c->own_off[t], (size_t)c->own_cnt[t], NCCL_DOUBLE, t, c->comm, s));
-            NCCLOK(R->Recv(c->tile_buf2 + c->tile_off[t], (size_t)c->tile_cnt[t], NCCL_DOUBLE, t, c->comm, s));
+            if (c->own_cnt[t]) NCCLOK(R->Send(c->own_out + c->own_off[t], (size_t)c->own_cnt[t], NCCL_DOUBLE, t, c->comm, s));
+            if (c->tile_cnt[t]) NCCLOK(R->Recv(c->tile_buf2 + c->tile_off[t], (size_t)c->tile_cnt[t], NCCL_DOUBLE, t, c->comm, s));
         }
         NCCLOK(grp.end());
         return ifc ? sx_iface_apply(h, c->tile_buf2) : sx_a2a_unpack_a(h, c->tile_buf2);
