@@ -287,7 +287,9 @@ def main():
     # the driver's `--warmup 5 --steps 20` the 20 timed steps would otherwise start 5 ms after the GPU left idle and run 4-5 %
     # below the steady state.  Measured step by step from an idle GPU (profiles/step_times.py, profiles/r03/step_times_from_idle.txt):
     # 1.02, 1.07, 1.16, 1.17, 1.18, 1.16, 1.13 ... ms, 1.00 ms from step 25 on, 0.99-1.01 ms steady - the device's power state,
-    # not the code (929-942 steps/s at W = 5 against 977-980 at W = 50 or 200).  After this run the GPU is in its working state
+    # not the code (929-942 steps/s at W = 5 against 977-980 at W = 50 or 200).  100 timed steps (a quarter of a second): with 30
+    # the first bench run on a freshly acquired box still read 957 against 970-973 for the next ones; with 100, 971 like the rest.
+    # After this run the GPU is in its working state
     # when the W warm-up steps begin.  `--no-native` skips it.
     native, runn = None, None
     if world == 1 and rank == 0 and args.workload == "rlz_513x256x64" and not args.no_native:
@@ -301,7 +303,7 @@ def main():
             for _ in range(10):
                 runn.step()
             torch.cuda.synchronize()
-            nsteps = max(5, min(args.steps, 30))
+            nsteps = 100 if args.steps >= 20 else max(5, args.steps)      # a quarter of a second of device time: also the pre-heat
             t1 = time.perf_counter()
             for _ in range(nsteps):
                 runn.step()

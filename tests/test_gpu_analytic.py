@@ -253,3 +253,73 @@ def test_gradient_wind_balanced_vortex_is_a_steady_state(set_name):
     print("\n%s: 48 cells ug %.2e dh %.2e dvg %.2e ub %.2f   96 cells ug %.2e dh %.2e dvg %.2e" % ((set_name,) + a + b[:3]))
     assert a[0] < 5e-4 and a[1] < 4e-4 and a[2] < 1e-3 and a[3] > 0.5
     assert a[0] / b[0] > 8.0 and b[1] < a[1] and b[2] < a[2]
+
+
+def decaying_wave_error(model_cls, num_cells, ts, steps, K=0.5, c0=1.0, m=3):
+    """LinearAdvection1D, u_t = -c_0 u_r + K u_rr (src/testModels.jl:1-20), PERIODIC on [-50, 50]: a sine of wavenumber
+    kappa = 2 pi m / 100 travels at c_0 and decays as exp(-K kappa^2 t).  (The notebook's known answer has K = 0.)"""
+    from tests import cases
+    kap = 2.0 * np.pi * m / 100.0
+    keep = {}
+
+    def ic(p):
+        keep["x"] = p[:, 0]
+        return np.sin(kap * p[:, 0])[:, None]
+    case = cases.kat_r(num_cells=num_cells)
+    case.update(par=dict(c_0=c0, K=K), ts=ts, ic=ic)
+    mdl = model_cls(case)
+    for _ in range(steps):
+        mdl.step()
+    u = mdl.physical()[:, 0, 0]
+    if hasattr(mdl, "run"):
+        mdl.run.close()
+    T = ts * steps
+    return np.abs(u - np.exp(-K * kap * kap * T) * np.sin(kap * (keep["x"] - c0 * T))).max(), np.exp(-K * kap * kap * T)
+
+
+def test_advected_and_diffused_sine_on_the_periodic_r_grid():
+    """The diffusion term's sign and scale (the d2/dr2 slot) together with advection and AB3: after T = 40 the wave has moved
+    1.2 wavelengths and decayed to 0.49 of its amplitude; the error (the per-step spline filter: 2e-7 per step at DX = 1)
+    falls with the cell size."""
+    from tests import cases
+    a, amp = decaying_wave_error(cases.HipModel, 100, 0.05, 800)
+    b, _ = decaying_wave_error(cases.HipModel, 200, 0.025, 1600)
+    print("\ndecaying wave: amplitude %.3f, error 100 cells %.2e, 200 cells %.2e" % (amp, a, b))
+    assert 0.4 < amp < 0.6 and a < 3e-4 and b < 7e-5 and a / b > 3.0
+
+
+def bessel_mode_error(model_cls, geometry, ring_L, ts=0.001, steps=400, K=0.2, m=2, kap=1.0):
+    """u = v = 0: LinearAdvectionRL / RLZ is h_t = K (h_r / r + h_rr + h_ll / r^2) (src/testModels.jl:48-98), and
+    J_m(kappa r) cos(m lambda) is an eigenfunction of that Laplacian: it decays as exp(-K kappa^2 t).  ts is bound by the
+    innermost ring (K ts / r_min^2 < 0.5 with r_min = 0.11 DX)."""
+    from scipy.special import jv
+    from tests import cases
+    grid = dict(geometry=geometry, xmin=0.0, xmax=16.0, num_cells=64, vars={"h": 1, "u": 2, "v": 3}, ring_L=ring_L)
+    if "Z" in geometry:
+        grid.update(zmin=0.0, zmax=ZMAX, zDim=12)
+    keep = {}
+
+    def ic(p):
+        r, lam = p[:, 0], p[:, 1]
+        z = p[:, 2] if "Z" in geometry else 0 * r
+        keep["r"], keep["h"] = r, jv(m, kap * r) * np.cos(m * lam + 0.3) * (1.0 + 0.1 * z)
+        return np.stack([keep["h"], 0 * r, 0 * r], axis=1)
+    mdl = model_cls(dict(name="bessel", grid=grid, eq="LinearAdvection" + geometry, ts=ts, par=dict(K=K), ic=ic))
+    for _ in range(steps):
+        mdl.step()
+    h = mdl.physical()[:, 0, 0]
+    if hasattr(mdl, "run"):
+        mdl.run.close()
+    inner = (keep["r"] > 0.5) & (keep["r"] < 14.0)      # away from the rings that truncate wavenumber 2 and from the open outer edge
+    exact = np.exp(-K * kap * kap * ts * steps) * keep["h"]
+    return np.abs(h - exact)[inner].max(), np.abs(exact - keep["h"])[inner].max()
+
+
+@pytest.mark.parametrize("geometry,ring_L", [("RL", None), ("RL", 64), ("RLZ", 32)])
+def test_bessel_mode_decays_at_the_rate_of_the_polar_laplacian(geometry, ring_L):
+    """The 1 / r and 1 / r^2 factors of the diffusion term, the d/dr, d2/dr2 and d2/dlambda2 slots that feed it: 400 steps change
+    the field by 0.037, the result is within 5e-5 of the closed form (0.13 % of the change)."""
+    from tests import cases
+    err, change = bessel_mode_error(cases.HipModel, geometry, ring_L)
+    print("\n%s ring_L=%s: changed by %.3f, error %.2e" % (geometry, ring_L, change, err))
+    assert change > 0.03 and err < 1e-4

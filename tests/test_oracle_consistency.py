@@ -314,3 +314,16 @@ def test_oracle_semiimplicit_standing_acoustic_wave_is_second_order_to_the_close
         b = T.standing_wave_errors(cls, 0.25, 80)
         assert a[0] < 6e-3 and a[1] < 4e-3
         assert 3.5 < a[0] / b[0] < 4.5 and 3.5 < a[1] / b[1] < 4.5
+
+
+def test_oracle_advected_and_diffused_sine_matches_the_closed_form():
+    from tests import test_gpu_analytic as T
+    a, amp = T.decaying_wave_error(cases.OracleModel, 100, 0.05, 800)
+    b, _ = T.decaying_wave_error(cases.OracleModel, 200, 0.025, 1600)
+    assert 0.4 < amp < 0.6 and a < 3e-4 and b < 7e-5 and a / b > 3.0
+
+
+def test_oracle_bessel_mode_decays_at_the_rate_of_the_polar_laplacian():
+    from tests import test_gpu_analytic as T
+    err, change = T.bessel_mode_error(cases.OracleModel, "RL", 64)
+    assert change > 0.03 and err < 1e-4
