@@ -692,7 +692,10 @@ static bool dft_planes(const sx_handle *h) { return !h->has_z; }
 bool dft_mfma_ok(const sx_handle *h) {
     if (!h->has_l || fft_path_ok(h)) return false;
     if (h->L_max > DFT_LMAX) return false;      // twiddle table (16 bytes per ring point) + staged chunks must fit 160 KB of LDS
-    if (dft_planes(h) ? (h->V > 8 || h->D > 5) : h->nz < 8) return false;
+    if (dft_planes(h) && (h->V > 8 || h->D > 5)) return false;
+    // fewer than 8 levels leave most of the MFMA N dimension empty: the scalar kernels then, as far as THEY reach (511 points,
+    // kmax 255); beyond that the matrix-core kernels run with a partial level chunk rather than refusing the grid
+    if (!dft_planes(h) && h->nz < 8 && h->L_max <= 511 && h->kmax_max <= 255) return false;
     static const bool off = getenv("SX_DFT_MFMA") && atoi(getenv("SX_DFT_MFMA")) == 0;       // scalar kernels instead (debugging)
     if (off) return false;
     return h->L_all_mult4;

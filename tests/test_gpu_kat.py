@@ -53,3 +53,17 @@ def test_notebook_known_answer_through_integrate_model(tmp_path, num_tiles):
     assert rel < 1e-11, rel
     l2 = np.sqrt(np.sum((initial[:, 1] - final[:, 1]) ** 2))
     assert abs(l2 / KAT["l2_norm"] - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("geometry,ring_L,tiles", [("RZ", None, 1), ("RL", 8, 1), ("RL", None, 1), ("RLZ", 8, 1), ("RLZ", None, 1),
+                                                   ("RLZ", 8, 2), ("RZ", None, 3)])
+def test_notebook_known_answer_on_rz_rl_rlz_grids(geometry, ring_L, tiles):
+    """The reference's only fixture carried through the azimuthal and vertical transform paths of the HIP library: the notebook's
+    equation posed on an RZ / RL / RLZ grid (tests/cases.py::kat_in_geometry; uniform rings = FFT kernels, native ragged rings up
+    to 1,204 points = DFT kernels, 1-3 tiles), 2000 steps, the printed values at every ring point and level."""
+    from tests import cases
+    m = cases.HipModel(cases.kat_in_geometry(geometry, ring_L=ring_L), num_tiles=tiles, exchange="a2a")
+    dev = cases.kat_deviation(m, KAT)
+    m.run.close()
+    print("\n%s ring_L=%s tiles=%d: max relative deviation from the notebook's values %.2e" % (geometry, ring_L, tiles, dev))
+    assert dev < 1e-11

@@ -443,6 +443,17 @@ def test_index_maps_reproduce_the_shared_sum(maker, kw, ntiles):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("num_cells,zDim", [(100, 4), (130, 4), (130, 6)])
+def test_native_rings_beyond_the_scalar_kernels_with_fewer_than_eight_levels(num_cells, zDim):
+    """RLZ grids with fewer than 8 levels take the scalar DFT kernels (most of the MFMA N dimension would be empty) - as far as
+    those reach (511 points).  Longer native rings (100 cells: 1,204 points, single-pass matrix-core kernels; 130 cells: 1,564
+    points, kmax 389, the chunked ones) run on the matrix cores with a partial level chunk; they used to be refused."""
+    case = cases.rlz_advection(num_cells=num_cells, zDim=zDim)
+    case["grid"]["xmax"] = 2.5 * num_cells / 4.0
+    assert _run(case, 2) < TOL
+
+
+@pytest.mark.gpu
 def test_rings_outside_every_transform_path_fail_loudly():
     """Ring lengths that no azimuthal kernel can take must be refused with a clear message - not fail in a launch with
     'invalid argument', and never compute something else.  (Native patches run up to 426 cells = rings of 5,112 points; the

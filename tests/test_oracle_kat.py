@@ -51,3 +51,11 @@ def test_textbook_quadrature_weights_do_not_reproduce_the_notebook(monkeypatch):
         ref.step()
         alt.step()
     assert cases.rel_err(alt.physical()[:, :, :1], ref.physical()[:, :, :1]) > 1e-5
+
+
+@pytest.mark.parametrize("geometry", ["RZ", "RL", "RLZ"])
+def test_notebook_known_answer_on_rz_rl_rlz_grids(geometry):
+    """The reference's fixture through the Fourier and Chebyshev paths: an axisymmetric, z-independent field advected by a unit
+    radial wind on an RZ / RL / RLZ grid obeys the notebook's equation at every (lambda, z) (tests/cases.py::kat_in_geometry)."""
+    m = cases.OracleModel(cases.kat_in_geometry(geometry))
+    assert cases.kat_deviation(m, KAT) < 1e-11
