@@ -1,0 +1,151 @@
+"""Seeded random configurations of the ABI against the C oracle: geometry x equation set x cells x levels x ring table x radial /
+vertical boundary conditions per variable x tiles x exchange protocol x filter length.  Every case is small (the oracle
+finishes in a fraction of a second); the point is the combinations nobody wrote a case for - that is how the refusal of
+few-level RLZ grids with long native rings was found (tests/test_gpu_parity.py::test_native_rings_beyond_the_scalar_*).
+
+Default: 48 cases (about 20 s on an MI355X).  SCYTHE_FUZZ=N runs N cases, SCYTHE_FUZZ_SEED moves the sequence,
+SCYTHE_FUZZ_SCALE=medium draws larger grids (seconds per case)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+RADIAL = ["R0", "R1T0", "R1T1", "R1T2", "R2T10", "R2T20", "R3"]
+VERTICAL = ["R0", "R1T0", "R1T1", "R1T2"]
+SETS = {"R": ["LinearAdvection1D"], "RZ": ["LinearAdvectionRZ", "LinearAcousticRZ"],
+        "RL": ["LinearAdvectionRL", "Oneway_ShallowWater_Slab", "Twoway_ShallowWater_Slab"],
+        "RLZ": ["LinearAdvectionRLZ", "Oneway_ShallowWater_HeightResolvedBL"]}
+VARS = {"LinearAdvection1D": {"u": 1}, "LinearAdvectionRZ": {"h": 1, "u": 2, "v": 3, "w": 4},
+        "LinearAcousticRZ": {"s": 1, "xi": 2, "mu": 3, "u": 4, "w": 5}, "LinearAdvectionRL": {"h": 1, "u": 2, "v": 3},
+        "LinearAdvectionRLZ": {"h": 1, "u": 2, "v": 3}, "Oneway_ShallowWater_Slab": cases.VARS6,
+        "Twoway_ShallowWater_Slab": cases.VARS6, "Oneway_ShallowWater_HeightResolvedBL": cases.VARS6}
+
+
+def draw(rng, medium=False):
+    """medium: patches of 40-110 cells (native rings to 1,324 points: both matrix-core DFT forms), 16-64 levels, uniform ring
+    tables of 96-512 points, up to 4 tiles - seconds per case in the oracle"""
+    geometry = rng.choice(["R", "RZ", "RL", "RLZ"], p=[0.05, 0.15, 0.3, 0.5] if medium else [0.15, 0.25, 0.25, 0.35])
+    eq = str(rng.choice(SETS[geometry]))
+    names = VARS[eq]
+    tiles = int(rng.choice([1, 1, 2, 3, 4] if medium else [1, 1, 2, 3]))
+    nc = int(rng.integers(3, 30)) if tiles == 1 else int(rng.integers(9 * tiles, 9 * tiles + 20))
+    if medium:
+        nc = int(rng.integers(40, 111))
+    periodic = geometry in ("R", "RZ") and rng.random() < 0.15
+    if periodic:
+        bcl = {k: "PERIODIC" for k in names}
+        bcr = dict(bcl)
+    else:
+        bcl = {k: str(rng.choice(RADIAL)) for k in names}
+        bcr = {k: str(rng.choice(RADIAL)) for k in names}
+    xmin = 0.0 if "L" in geometry else float(rng.choice([0.0, -3.0, 2.0]))
+    grid = dict(geometry=geometry, xmin=xmin, xmax=xmin + float(rng.uniform(0.3, 1.5)) * nc, num_cells=nc, vars=names, BCL=bcl, BCR=bcr,
+                l_q=float(rng.choice([2.0, 2.0, 1.5, 3.0])))
+    if "Z" in geometry:
+        nz = int(rng.choice([16, 32, 64, 20] if medium else [4, 5, 7, 8, 10, 12, 16, 17, 24, 32]))
+        if eq == "Oneway_ShallowWater_HeightResolvedBL":
+            nz = max(nz, 6)
+        grid.update(zmin=0.0, zmax=float(rng.uniform(1.0, 4.0)), zDim=nz)
+        if eq == "LinearAcousticRZ":
+            grid.update(b_zDim=nz, BCB={"w": "R1T0"}, BCT={"w": "R1T0"})
+        else:
+            grid.update(BCB={k: str(rng.choice(VERTICAL)) for k in names}, BCT={k: str(rng.choice(VERTICAL)) for k in names})
+            if rng.random() < 0.3:
+                grid.update(b_zDim=int(rng.integers(max(3, nz // 2), nz + 1)))
+    if "L" in geometry:
+        grid.update(ring_L=rng.choice([None, None, 128, 256, 512, 96, 200] if medium else [None, None, 8, 16, 32, 64, 12, 20, 10, 6]))
+        if grid["ring_L"] is not None:
+            grid["ring_L"] = int(grid["ring_L"])
+    seed = int(rng.integers(1 << 30))
+    xm, xM = grid["xmin"], grid["xmax"]
+    zM = grid.get("zmax", 1.0)
+
+    def ic(p):
+        r = p[:, 0]
+        lam = p[:, 1] if "L" in geometry else 0 * r
+        z = p[:, -1] if "Z" in geometry else 0 * r
+        g = np.random.default_rng(seed)
+        out = []
+        for _ in names:
+            a = g.uniform(-1, 1, 6)
+            s = (r - xm) / (xM - xm)
+            f = a[0] + a[1] * np.sin(2.1 * s + a[2]) + 0.3 * a[3] * np.cos(lam + a[4]) * s + 0.2 * a[5] * np.sin(2 * lam) * s * s
+            out.append(f * (1.0 + 0.3 * np.cos(1.3 * z / zM + a[2])))
+        v = np.stack(out, axis=1)
+        if eq.endswith("HeightResolvedBL") or eq.endswith("Slab"):
+            v[:, 0] *= 10.0            # h of a few metres on Hfree = 2000 m
+        if eq == "LinearAcousticRZ":
+            v[:, 1] *= 1e-3
+        return v
+    par = {"LinearAdvection1D": dict(c_0=0.5, K=0.01), "LinearAcousticRZ": dict(K=0.01, Pxi_bar=50.0)}.get(eq)
+    if par is None:
+        par = dict(cases.SW_PAR) if ("Shallow" in eq) else dict(K=0.003)
+        if "Shallow" in eq:
+            par.update(K=0.01, Kh=0.01, f=0.05, g=0.1, Hfree=20.0, Hb=10.0)
+    case = dict(name="fuzz", grid=grid, eq=eq, ts=0.002, par=par, ic=ic, semiimplicit=(eq == "LinearAcousticRZ"))
+    exchange = str(rng.choice(["a2a", "gather", "iface"])) if tiles > 1 else "a2a"
+    impl = str(rng.choice(["torch", "lib"])) if tiles > 1 else "torch"
+    return case, tiles, exchange, impl
+
+
+def describe(case, tiles, exchange, impl):
+    g = case["grid"]
+    return "%s %s cells=%d zDim=%s b_zDim=%s ring_L=%s l_q=%s tiles=%d/%s/%s BCL=%s BCR=%s BCB=%s BCT=%s" % (
+        g["geometry"], case["eq"], g["num_cells"], g.get("zDim"), g.get("b_zDim"), g.get("ring_L"), g["l_q"], tiles, exchange, impl,
+        list(g["BCL"].values()), list(g["BCR"].values()), list(g.get("BCB", {}).values()), list(g.get("BCT", {}).values()))
+
+
+def run_case(case, tiles, exchange, impl, steps=3):
+    import scythe_jl_amd as S
+    try:
+        hip = cases.HipModel(case, num_tiles=tiles, exchange=exchange, impl=impl)
+    except S.ScytheHipError as e:
+        # a refusal must be one of the documented ones, never a crash or a wrong answer
+        msg = str(e)
+        assert any(k in msg for k in ("too few cells", "fewer than 6 free", "outside every transform path", "at least 9 cells",
+                                      "cells per tile", "must be even")), msg
+        return None
+    orc = cases.OracleModel(case)
+    for _ in range(steps):
+        hip.step()
+        orc.step()
+    a, b = hip.physical(), orc.physical()
+    hip.run.close()
+    if not np.isfinite(b).all() or np.abs(b[:, :, 0]).max() > 1e4:
+        return "unstable"           # random fields on a random grid may simply blow up (in the oracle as well): not a parity case
+    return cases.rel_err_per_var(a[:, :, :1], b[:, :, :1]), cases.rel_err_per_var(a, b)
+
+
+def test_seeded_random_configurations_against_the_oracle():
+    n = int(os.environ.get("SCYTHE_FUZZ", "48"))
+    rng = np.random.default_rng(int(os.environ.get("SCYTHE_FUZZ_SEED", "20261004")))
+    bad, refused, unstable, worst = [], 0, 0, (0.0, 0.0)
+    medium = os.environ.get("SCYTHE_FUZZ_SCALE", "") == "medium"
+    for i in range(n):
+        case, tiles, exchange, impl = draw(rng, medium)
+        what = describe(case, tiles, exchange, impl)
+        try:
+            res = run_case(case, tiles, exchange, impl, steps=2 if medium else 3)
+            if medium:
+                print(i, what[:150], res, flush=True)
+        except Exception as e:                                   # keep going: report every failing combination at once
+            bad.append("%d: %s\n      %s: %s" % (i, what, type(e).__name__, str(e)[:300]))
+            continue
+        if res is None:
+            refused += 1
+            continue
+        if res == "unstable":
+            unstable += 1
+            continue
+        worst = (max(worst[0], res[0]), max(worst[1], res[1]))
+        # values 1e-10; derivative slots 1e-8 (second derivatives of two correct fp64 runs differ by N^4 eps along z)
+        if not (res[0] < 1e-10 and res[1] < 1e-8):
+            bad.append("%d: %s\n      values %.2e slots %.2e" % (i, what, res[0], res[1]))
+    print("\n%d cases, %d refused with a documented message, %d unstable in the oracle too, worst values %.2e, worst slots %.2e"
+          % (n, refused, unstable, worst[0], worst[1]))
+    assert refused + unstable <= n // 3
+    assert not bad, "\n" + "\n".join(bad)
