@@ -469,3 +469,40 @@ def test_rings_outside_every_transform_path_fail_loudly():
             g.spectralTransform_()
     finally:
         g.close()
+
+
+@pytest.mark.gpu
+def test_two_handles_driven_from_two_host_threads():
+    """include/scythe_hip.h: calls on ONE handle are serial, different handles may be driven concurrently (the reference keeps one
+    mtile per worker process).  Two models stepped from two Python threads (ctypes drops the GIL inside the library) must give
+    bit for bit what each gives alone; the error text is per thread."""
+    import threading
+    import scythe_jl_amd as S
+
+    def solo(case, steps):
+        m = cases.HipModel(case)
+        for _ in range(steps):
+            m.step()
+        out = m.physical().copy()
+        m.run.close()
+        return out
+    ca, cb = cases.rlz_hrbl(num_cells=9, zDim=32, ring_L=32), cases.rl_slab(num_cells=20)
+    ra, rb = solo(ca, 6), solo(cb, 40)
+    assert np.isfinite(ra).all() and np.isfinite(rb).all()
+    got, errs = {}, []
+
+    def work(name, case, steps):
+        try:
+            got[name] = solo(case, steps)
+            # a failing call on this thread must not disturb the other thread's handle or message
+            with pytest.raises(S.ScytheHipError, match="too few cells"):
+                cases.HipModel(cases.r_bcs(bcl="R3", bcr="R3", num_cells=4))
+        except BaseException as e:       # noqa: BLE001 - reported by the main thread
+            errs.append((name, e))
+    ts = [threading.Thread(target=work, args=("a", ca, 6)), threading.Thread(target=work, args=("b", cb, 40))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert np.array_equal(got["a"], ra) and np.array_equal(got["b"], rb)
