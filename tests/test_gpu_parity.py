@@ -506,3 +506,40 @@ def test_two_handles_driven_from_two_host_threads():
         t.join()
     assert not errs, errs
     assert np.array_equal(got["a"], ra) and np.array_equal(got["b"], rb)
+
+
+@pytest.mark.gpu
+def test_create_destroy_cycles_return_the_device_memory():
+    """sx_destroy (and the release of the exchange state) give back everything sx_create, the timers and the exchange buffers took:
+    40 create / step / close cycles - one tile, three tiles with each exchange protocol through the library's loopback transport
+    - leave the free device memory where it was (hipMemGetInfo; one allocation granule of slack) and the host's resident set too."""
+    import torch
+
+    def cycle(i):
+        kind = i % 4
+        case = cases.rlz_hrbl(num_cells=27, zDim=32, ring_L=64)
+        if kind == 0:
+            m = cases.HipModel(case)
+        else:
+            m = cases.HipModel(case, num_tiles=3, exchange=["a2a", "gather", "iface"][kind - 1], impl="lib")
+        m.run.tiles[0].enable_timers(True)
+        for _ in range(3):
+            m.step()
+        m.physical()
+        m.run.close()
+    for i in range(4):                     # first use of every path: code objects, the library's lazily created state
+        cycle(i)
+    import gc
+    import psutil
+    torch.cuda.synchronize()
+    gc.collect()
+    free0, rss0 = torch.cuda.mem_get_info()[0], psutil.Process().memory_info().rss
+    for i in range(40):
+        cycle(i)
+    torch.cuda.synchronize()
+    gc.collect()
+    free1, rss1 = torch.cuda.mem_get_info()[0], psutil.Process().memory_info().rss
+    assert free0 - free1 <= (2 << 20), "device memory lost over 40 cycles: %.1f MB" % ((free0 - free1) / 2 ** 20)
+    # host side: operator tables, work lists, timer events (a cycle builds ~15 MB of them; 40 leaked cycles would be 600 MB)
+    assert rss1 - rss0 < (100 << 20), "host memory grew by %.0f MB over 40 cycles" % ((rss1 - rss0) / 2 ** 20)
+    print("\n40 cycles: device memory %+.2f MB, host RSS %+.1f MB" % ((free1 - free0) / 2 ** 20, (rss1 - rss0) / 2 ** 20))
