@@ -182,6 +182,20 @@ def test_bench_cli_two_ranks_rccl():
         assert d["config"]["exchange_selfcheck_max_rel_diff"] < 1e-12
 
 
+def _drawn_case(seed, index):
+    """draw number `index` of tests/test_gpu_fuzz.py's sequence for `seed` with more than one tile: (case, tiles, exchange)"""
+    import numpy as np
+    from tests import test_gpu_fuzz as F
+    rng = np.random.default_rng(seed)
+    k = -1
+    while True:
+        case, tiles, exchange, _ = F.draw(rng)
+        if tiles > 1:
+            k += 1
+            if k == index:
+                return case, tiles, exchange
+
+
 # ----------------------------------------------------------------------------- the in-library exchange with MORE THAN ONE rank
 def _fake_worker(rank, world, lib_path, uid, exchange, case_name, case_kw, q):
     """One process = one tile = one rank of sx_comm_init / sx_exchange; no torch.distributed anywhere: the only thing the ranks
@@ -189,7 +203,10 @@ def _fake_worker(rank, world, lib_path, uid, exchange, case_name, case_kw, q):
     os.environ["SX_RCCL_LIB"] = lib_path            # before the library binds its transport
     import scythe_jl_amd as S
     from tests import cases
-    case = getattr(cases, case_name)(**case_kw)
+    if case_name == "fuzz":                        # a drawn configuration (closures do not cross a spawn: every rank redraws it)
+        case = _drawn_case(**case_kw)[0]
+    else:
+        case = getattr(cases, case_name)(**case_kw)
     gp, mp_ = cases.hip_params(case)
     run = S.ModelRun(mp_, num_tiles=world, rank=rank, device="cuda", use_dist=True, exchange=exchange, impl="lib", unique_id=uid)
     tile = run.tiles[0]
@@ -290,3 +307,38 @@ def test_exchange_set_up_rejects_bad_tile_tables_in_every_mode(mode):
     finally:
         for g in tiles:
             g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("index", range(int(os.environ.get("SCYTHE_FUZZ_RANKS", "4"))))
+def test_drawn_configurations_with_ranks_in_separate_processes(tmp_path, index):
+    """tests/test_gpu_fuzz.py's random configurations (2-3 tiles, any exchange protocol, random boundary conditions and grid
+    sizes) with every tile a RANK in its own process, the exchange inside the library over the stand-in transport."""
+    import subprocess
+    import scythe_jl_amd as S
+    from tests import cases
+    case, world, exchange = _drawn_case(4711, index)
+    try:       # the same tiles in THIS process first (loopback transport): a configuration the library refuses is not sent to ranks
+        cases.HipModel(case, num_tiles=world, exchange=exchange, impl="lib").run.close()
+    except S.ScytheHipError as e:
+        pytest.skip("refused: %s" % e)
+    lib = str(tmp_path / "libfake_rccl.so")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O1", "-shared", "-fPIC", "-o", lib, os.path.join(root, "tests", "fake_rccl.cpp"), "-lrt"],
+                   check=True, capture_output=True)
+    uid = ("/sxfake_%d_%s" % (os.getpid(), os.urandom(4).hex())).encode().ljust(128, b"\0")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fake_worker, args=(r, world, lib, uid, exchange, "fuzz", {"seed": 4711, "index": index}, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+    for p in procs:
+        if p.is_alive():                 # exactly the processes started above
+            p.terminate()
+            p.join(20)
+    assert [p.exitcode for p in procs] == [0] * world
+    res = dict(q.get(timeout=5) for _ in range(world))
+    print("\n%s %s cells=%d ranks=%d %s: %s" % (case["grid"]["geometry"], case["eq"], case["grid"]["num_cells"], world, exchange, res))
+    assert max(res.values()) < 1e-8, res
