@@ -77,8 +77,8 @@ def cpu_baseline(workload, sample_cells, steps):
     sample_cells > 0: that many cells from the middle of the patch with the full azimuthal x vertical extent, plus the
     full-patch B->A solve, scaled to the grid - an extrapolation, kept for quick runs and reported beside the measurement."""
     from oracle import oracle_np as O, oracle_c as OC
-    # the GPU box's CPU share for one GPU is 16 cores; an OMP_NUM_THREADS given by the caller wins
-    OC.lib().orc_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", min(16, os.cpu_count() or 1))))
+    # the CPUs this container may use (the GPU box: a quota of 16 out of 256 visible); an OMP_NUM_THREADS given by the caller wins
+    OC.lib().orc_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", OC.usable_cpus())))
     kw, L = grid_kwargs(workload)
     g = O.Grid(kw.pop("geometry"), kw.pop("xmin"), kw.pop("xmax"), kw.pop("num_cells"), kw.pop("vars"), ring_L=L, **kw)
 

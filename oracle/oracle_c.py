@@ -34,6 +34,20 @@ def build(force=False):
     return so
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the scheduler affinity, cut down to the cgroup's CPU quota.  The GPU boxes show all
+    256 host CPUs to a container that owns 16 of them through a quota; OpenMP's default of one thread per VISIBLE CPU made a
+    step of the C port 8 x slower there (4.8 s against 0.6 s with 16 threads, 40-cell RLZ patch)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -42,6 +56,8 @@ def lib():
             build()
         _LIB = C.CDLL(so)
         _LIB.orc_num_threads.restype = C.c_int
+        if "OMP_NUM_THREADS" not in os.environ:
+            _LIB.orc_set_num_threads(usable_cpus())
         _LIB.orc_ops_phi.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, P_D, P_D]
         _LIB.orc_ops_wq.argtypes = [C.c_double, P_D]
         _LIB.orc_ops_spline_class.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, P_I, P_I, P_I, P_I, P_D, P_D, P_D, P_D]
