@@ -347,18 +347,19 @@ class Grid:
     def gridpoints(self, cell0=0, ncells=None):
         ncells = self.nc if ncells is None else ncells
         r = mish_points(self.xmin, self.DX, cell0, ncells)
-        cols = []
         zc = self.cheb(self.names[0]).z if self.has_z else np.zeros(1)
+        nz = self.zDim
+        blocks = []            # one block per ring: point order (l, z), z fastest - per element the same operations as a scalar loop
         for i, ring in enumerate(self.tile_rings(cell0, ncells)):
-            for l in range(self.L[ring]):
-                for z in range(self.zDim):
-                    row = [r[i]]
-                    if self.has_l:
-                        row.append(self.off[ring] + 2.0 * np.pi * l / self.L[ring])
-                    if self.has_z:
-                        row.append(zc[z])
-                    cols.append(row)
-        out = np.array(cols)
+            L = int(self.L[ring])
+            cols = [np.full(L * nz, r[i])]
+            if self.has_l:
+                lam = self.off[ring] + 2.0 * np.pi * np.arange(L) / L
+                cols.append(np.repeat(lam, nz))
+            if self.has_z:
+                cols.append(np.tile(zc[:nz], L))
+            blocks.append(np.stack(cols, axis=1))
+        out = np.concatenate(blocks, axis=0)
         return out[:, 0] if out.shape[1] == 1 else out
 
     # -- forward: tile physical values [N_t, V] -> tile B coefficients, reference tile layout
