@@ -3,7 +3,7 @@ vertical boundary conditions per variable x tiles x exchange protocol x filter l
 finishes in a fraction of a second); the point is the combinations nobody wrote a case for - that is how the refusal of
 few-level RLZ grids with long native rings was found (tests/test_gpu_parity.py::test_native_rings_beyond_the_scalar_*).
 
-Default: 48 cases (about 20 s on an MI355X).  SCYTHE_FUZZ=N runs N cases, SCYTHE_FUZZ_SEED moves the sequence,
+Default: 96 cases (about 25 s on an MI355X).  SCYTHE_FUZZ=N runs N cases, SCYTHE_FUZZ_SEED moves the sequence,
 SCYTHE_FUZZ_SCALE=medium draws larger grids (seconds per case), =fast the shapes of the tuned kernels with random per-handle
 switches, SCYTHE_FUZZ_STORAGE=f32 runs the fp32-storage mode against its
 declared bars."""
@@ -171,7 +171,7 @@ def run_case(case, tiles, exchange, impl, steps=3, storage="f64"):
 
 
 def test_seeded_random_configurations_against_the_oracle():
-    n = int(os.environ.get("SCYTHE_FUZZ", "48"))
+    n = int(os.environ.get("SCYTHE_FUZZ", "96"))
     rng = np.random.default_rng(int(os.environ.get("SCYTHE_FUZZ_SEED", "20261004")))
     bad, refused, unstable, worst = [], 0, 0, (0.0, 0.0)
     medium = os.environ.get("SCYTHE_FUZZ_SCALE", "") == "medium"
