@@ -179,6 +179,10 @@ def test_seeded_random_configurations_against_the_oracle():
     # f32: the value bar is the declared one; the slot bar is NOT the 5e-5 of the hand-written cases: on native rings with kmax ~ 100
     # and rough random fields the k^2-amplified echo of a 5-8e-8 value error reaches 2e-4 of the d2/dlambda2 slot (2 of 200 draws)
     tol = (1e-10, 1e-8) if storage == "f64" else (1e-6, 1e-3)
+    if medium and storage == "f64":
+        # native rings with kmax ~ 300: d2/dlambda2 of two correct fp64 states differs by kmax^2 x their last-bit differences
+        # (1.2e-8 in one of 140 medium draws, with the fields at 3e-12; DESIGN.md 2 "Derivative slots: measured, not assumed")
+        tol = (1e-10, 1e-7)
     fast = os.environ.get("SCYTHE_FUZZ_SCALE", "") == "fast"
     for i in range(n):
         flags = {}
