@@ -5,7 +5,7 @@ few-level RLZ grids with long native rings was found (tests/test_gpu_parity.py::
 
 Default: 96 cases (about 25 s on an MI355X).  SCYTHE_FUZZ=N runs N cases, SCYTHE_FUZZ_SEED moves the sequence,
 SCYTHE_FUZZ_SCALE=medium draws larger grids (seconds per case), =fast the shapes of the tuned kernels with random per-handle
-switches, SCYTHE_FUZZ_STORAGE=f32 runs the fp32-storage mode against its
+switches, SCYTHE_FUZZ_TILES=N draws 2..N tiles for every case, SCYTHE_FUZZ_STORAGE=f32 runs the fp32-storage mode against its
 declared bars."""
 import os
 
@@ -34,6 +34,8 @@ def draw(rng, medium=False):
     eq = str(rng.choice(SETS[geometry]))
     names = VARS[eq]
     tiles = int(rng.choice([1, 1, 2, 3, 4] if medium else [1, 1, 2, 3]))
+    if os.environ.get("SCYTHE_FUZZ_TILES"):           # many small tiles: 2 .. N (the interface-only solve takes up to 16)
+        tiles = int(rng.integers(2, int(os.environ["SCYTHE_FUZZ_TILES"]) + 1))
     nc = int(rng.integers(3, 30)) if tiles == 1 else int(rng.integers(9 * tiles, 9 * tiles + 20))
     if medium:
         nc = int(rng.integers(40, 111))
