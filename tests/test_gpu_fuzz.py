@@ -224,3 +224,38 @@ def test_seeded_random_configurations_against_the_oracle():
           % (n, refused, unstable, worst[0], worst[1]))
     assert refused + unstable <= n // 2
     assert not bad, "\n" + "\n".join(bad)
+
+
+def test_drawn_configurations_restart_bit_identically(tmp_path):
+    """save_checkpoint at a random step -> a fresh run that loads it continues exactly like the uninterrupted one (AB3 history
+    included), over drawn configurations: every geometry, equation set, exchange protocol and transport the draw produces."""
+    import scythe_jl_amd as S
+    n = int(os.environ.get("SCYTHE_FUZZ_RESTART", "16"))
+    rng = np.random.default_rng(int(os.environ.get("SCYTHE_FUZZ_SEED", "20261004")) + 1)
+    done, bad = 0, []
+    for i in range(4 * n):
+        if done == n:
+            break
+        case, tiles, exchange, impl = draw(rng)
+        k, more = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+        try:
+            a = cases.HipModel(case, num_tiles=tiles, exchange=exchange, impl=impl)
+        except S.ScytheHipError:
+            continue
+        for _ in range(k):
+            a.step()
+        ck = str(tmp_path / ("ck%d.npz" % i))
+        a.run.save_checkpoint(ck)
+        for _ in range(more):
+            a.step()
+        b = cases.HipModel(case, num_tiles=tiles, exchange=exchange, impl=impl)
+        b.run.load_checkpoint(ck)
+        for _ in range(more):
+            b.step()
+        pa, pb = a.physical(), b.physical()
+        a.run.close()
+        b.run.close()
+        done += 1
+        if not np.array_equal(pa, pb, equal_nan=True):
+            bad.append("%d: %s, checkpoint after step %d, %d more" % (i, describe(case, tiles, exchange, impl), k, more))
+    assert done == n and not bad, "\n".join(bad)
