@@ -1,21 +1,15 @@
-# INTEGRATION — binding libscythe_hip.so from Scythe.jl
+# hipTile.jl - binding libscythe_hip.so (include/scythe_hip.h) from Scythe.jl.
+#
+# The file a maintainer would add as src/hipTile.jl and include from src/Scythe.jl after semiimplicit.jl; it is the text of
+# INTEGRATION.md sections 1-4.  NEVER EXECUTED: there is no julia in the image this repository is built and tested in.  What IS
+# checked (tests/test_abi.py, CPU): the field offsets that Julia's layout rule for isbits structs (C layout: every field at
+# the next multiple of its own alignment) gives the three structs below equal the C compiler's offsetof() for the header's
+# structs, and so does the table SX_ABI_OFFSETS, which sx_check_layout() compares with fieldoffset() when the file is loaded.
+#
+# Replaces: createModelTile (src/semiimplicit.jl:44-124), advanceTimestep (:301-332, called :276), splineTransform! (called :285),
+# the patchSpectral pull of the output path (:289-290).  integrate_model / initialize_model / run_model / model_loop stay as they are.
 
-The reference is Julia and has no FFI for this path. The seam is the pair of remote calls the master issues per step
-(`src/semiimplicit.jl:276` `advanceTimestep`, `:285` `splineTransform!`) plus `createModelTile` (`:44`) at start-up and
-the `tileTransform!` used for output (`:289-290`). Everything above that (`integrate_model`, `initialize_model`,
-`run_model`, `model_loop`, model files, `run_Scythe.jl`) stays as it is.
-
-**Status: the Julia glue below has never been executed** — there is no `julia` in the build image or on the GPU box.
-It is the binding a maintainer would add (a new file `src/hipTile.jl`, included from `src/Scythe.jl` after
-`semiimplicit.jl`); the same text is committed as **`julia/hipTile.jl`** (`tests/test_abi.py` checks that every line of the
-blocks below is in that file, and - the one thing a `ccall` user can get wrong that nothing else here would see - that the
-field OFFSETS Julia's layout rule gives `SxGridDesc` / `SxModelDesc` / `SxDims` equal the C compiler's `offsetof` for
-`sx_grid_desc` / `sx_model_desc` / `sx_dims`, and the table `SX_ABI_OFFSETS` the file checks itself against with `fieldoffset` at load time). The same ABI is exercised end to end by the Python mirror in `scythe.jl_amd/` (ctypes), which is what
-the tests and `bench.py` drive.
-
-## 1. Descriptors
-
-```julia
+# ---- 1. descriptors ----------------------------------------------------------------------------------------------------------
 const libsx = "libscythe_hip.so"            # on LD_LIBRARY_PATH, or an absolute path
 
 struct SxGridDesc                           # mirrors sx_grid_desc (include/scythe_hip.h), field for field
@@ -53,11 +47,8 @@ function sx_bc(d::Dict)                     # CubicBSpline.* / Chebyshev.* Dict 
 end
 
 sxcheck(rc) = rc == 0 || error(unsafe_string(ccall((:sx_last_error, libsx), Cstring, ())))
-```
 
-## 2. A GPU-resident ModelTile
-
-```julia
+# ---- 2. a GPU-resident ModelTile ---------------------------------------------------------------------------------------------
 mutable struct HipModelTile                 # replaces ModelTile (src/semiimplicit.jl:18-42) on a worker
     handle::Ptr{Cvoid}
     model::ModelParameters
@@ -110,11 +101,33 @@ function createHipModelTile(patch::AbstractGrid, tile_params::Matrix, model::Mod
 end
 # run_model (:222-226) hands every tile the map of what it receives, exactly as it does with haloReceiveIndexMap today:
 #   mtile(w+1).haloRecvIndex = get_val_from(w, :(mtile.patchHalo))        (the first tile receives nothing)
-```
 
-## 3. The two per-step calls
+# ---- layout self-check ------------------------------------------------------------------------------------------------------
+# byte offsets of every field as the C compiler lays out include/scythe_hip.h on x86-64 / gfx950 hosts (LP64)
+const SX_ABI_OFFSETS = Dict(
+    :SxGridDesc => (abi_version = 0, geometry = 4, xmin = 8, xmax = 16, num_cells = 24, l_q = 32, nvars = 40, bcl = 48, bcl_k0 = 56,
+                    bcr = 64, zmin = 72, zmax = 80, zDim = 88, b_zDim = 92, bcb = 96, bct = 104, ring_uniform_L = 112, tile_cell0 = 116,
+                    tile_num_cells = 120, tile_num = 124, storage_f32 = 128, sizeof = 136),
+    :SxModelDesc => (ts = 0, equation_set = 8, semiimplicit = 12, params = 16, w_index = 24, xi_index = 28, col_var = 32,
+                     ref_state = 40, sizeof = 48),
+    :SxDims => (n_points = 0, n_hpoints = 8, n_vars = 16, n_derivs = 20, n_coord = 24, rDim = 28, b_rDim = 32, tile_rDim = 36,
+                tile_b_rDim = 40, zDim = 44, b_zDim = 48, kDim = 52, n_blocks = 56, tile_kDim = 60, tile_n_blocks = 64, s_patch = 72,
+                s_tile = 80, n_cols = 88, sizeof = 96),
+)
 
-```julia
+function sx_check_layout()
+    for (T, name) in ((SxGridDesc, :SxGridDesc), (SxModelDesc, :SxModelDesc), (SxDims, :SxDims))
+        want = SX_ABI_OFFSETS[name]
+        for (i, f) in enumerate(fieldnames(T))
+            fieldoffset(T, i) == getfield(want, f) || error("$name.$f is at byte $(fieldoffset(T, i)), the C header has it at $(getfield(want, f))")
+        end
+        sizeof(T) == want.sizeof || error("sizeof($name) = $(sizeof(T)), the C header says $(want.sizeof)")
+    end
+    ccall((:sx_abi_version, libsx), Cint, ()) == 2 || error("libscythe_hip.so has another SX_ABI_VERSION than this file (2)")
+    return true
+end
+
+# ---- 3. the two per-step calls (host hop through the reference's SharedArray / RemoteChannel protocol) ----------------------
 # advanceTimestep(mtile, sharedSpectral, haloSend, haloReceive, t)   (src/semiimplicit.jl:301-332)
 # Drop-in that keeps the reference's SharedArray + RemoteChannel protocol (host hop; simplest to adopt):
 function advanceTimestep(mtile::HipModelTile, sharedSpectral::SharedArray{Float64},
@@ -143,20 +156,8 @@ function patchSpectral(mtile::HipModelTile)
                   mtile.handle, mtile.patchSpectral))
     return mtile.patchSpectral
 end
-```
 
-`model_loop` then issues exactly the remote calls it issues today
-(`get_from(w, :(advanceTimestep(mtile, sharedSpectral, haloSend, haloReceive, $t)))`,
-`get_from(w, :(splineTransform!(mtile, sharedSpectral)))`).  Every name used above is defined here or in the reference:
-the index vectors come from `sx_index_maps` (tested against the oracle's shared-sum protocol,
-`tests/test_gpu_parity.py::test_index_maps_reproduce_the_shared_sum`), `SharedArray` / `RemoteChannel` are the reference's.
-
-## 4. Keeping the exchange on the device (what `bench.py` measures)
-
-The host hop above moves the tile's B coefficients through PCIe every step. With one worker process per GPU the library
-does the whole exchange itself, over RCCL, on the handle's stream (`csrc/sx_comm.cpp`); the Julia side shrinks to:
-
-```julia
+# ---- 4. the exchange on the device (RCCL inside the library; what bench.py measures) -----------------------------------------
 # once, after createHipModelTile on every worker.  cell0 / ncells = calcTileSizes rows 4 (spectralIndexL - 1) and 3 of every tile.
 # mode 2: interface-only solve (least traffic; needs >= 9 cells per tile); 0: transposed solve; 1: the reference's halo + gather
 function sx_comm_setup!(mtile::HipModelTile, ntiles::Integer, mytile::Integer, cell0::Vector{Int32}, ncells::Vector{Int32},
@@ -177,50 +178,3 @@ function advanceTimestepDevice(mtile::HipModelTile, t::Int64)
     sxcheck(ccall((:sx_advance, libsx), Cint, (Ptr{Cvoid}, Int32), mtile.handle, t))
     sxcheck(ccall((:sx_exchange, libsx), Cint, (Ptr{Cvoid},), mtile.handle))
 end
-```
-
-A host that wants to fall back cleanly when one worker cannot set the exchange up (no librccl, a tile too small for mode 2)
-calls `sx_comm_prepare(h, n, me, cell0, ncells, mode)` first - the non-collective part: librccl bound, tile table checked,
-buffers allocated - lets the master collect the return codes, and enters the collective `sx_comm_init` on every worker or on
-none.  `sx_comm_attach(h, n, me, cell0, ncells, mode, comm)` does the same with an `ncclComm_t` the host already owns (e.g. from
-NCCL.jl built against librccl).  librccl is bound with `dlopen` on first use (`SX_RCCL_LIB` overrides the search); a process
-that never calls `sx_comm_*` never loads it.  The building blocks stay exported for hosts that want to drive the
-communication themselves (`sx_bind_tile_b`, `sx_halo_add`, `sx_bind_patch_b`, `sx_a2a_configure`, `sx_a2a_pack_b`,
-`sx_a2a_solve`, `sx_a2a_unpack_a`, `sx_iface_configure`, `sx_iface_local`, `sx_iface_reduce`, `sx_iface_apply`, `sx_set_stream`;
-the Python driver's `torch.distributed` variant uses exactly these), and
-`sx_comm_init_local` / `sx_exchange_local` run the same exchange between several handles of one process on one GPU.
-
-## 5. Other entry points
-
-| call | replaces / adds |
-|---|---|
-| `sx_get_state` / `sx_set_state` / `sx_state_size` | restart with the AB3 history (the reference restarts from `physical_out_*.csv` only) |
-| `sx_check_nan`, `sx_max_abs` | `checkCFL` (`src/semiimplicit.jl:737-751`) and a per-variable max for a CFL number, reduced on the device |
-| `sx_cheb_column_ops` | Springsteel's `Chebyshev1D` column operations as dense matrices, for `interpolate_reference_file` / `transform_reference_state!` (`src/reference_state.jl`) — the Python mirror is `scythe.jl_amd/reference_state.py`; in Julia the existing `reference_state.jl` can stay and only its result be passed through `sx_model_desc.ref_state` |
-| `sx_enable_timers` / `sx_timer_only` / `sx_get_timers` / `sx_kernel_bytes` | per-kernel hipEvent timing (optionally only one kernel's pair, to keep the stream free of the other event records) and algorithmic bytes (what `bench.py` reports) |
-| `sx_index_map_sizes` / `sx_index_maps` | `calcPatchMap` / `calcHaloMap` (`src/semiimplicit.jl:79-86`) as linear indices, §2 |
-
-## 6. Build / load
-
-`python -c "import __graft_entry__ as g; g.build()"` runs `make -C scythe.jl_amd/csrc clean` and `make -C scythe.jl_amd/csrc -j6`
-(always from scratch, half a minute; the build is bit-reproducible wherever the tree is checked out): one
-`hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Iinclude -c` per source (`sx_api.cpp sx_setup.cpp sx_comm.cpp
-sx_kernels.hip sx_fft.hip sx_dft.hip sx_iface.hip`) and `hipcc -shared -o scythe.jl_amd/libscythe_hip.so ... -ldl`.  The
-library's RUNPATH is `/opt/rocm-7.2.0/lib`: a host without PyTorch (Julia, or the C program below) gets the HIP runtime and,
-through `dlopen`, librccl from there.  When the library shares a process with PyTorch-ROCm, import torch first: torch bundles
-its own `libamdhip64.so` with the same SONAME, and two HIP runtimes in one process leave the second without a device
-(`scythe.jl_amd/_lib.py` does this).
-
-## 7. The closest thing to the Julia host that runs here
-
-`tests/abi_host.c` is a plain C program (gcc, `dlopen`, no Python, no torch in the process) that makes exactly the calls of
-§2-§4 - `sx_create` → `sx_get_gridpoints` → `sx_set_physical_values` → `sx_spectral_transform` → exchange →
-per step `sx_advance` + `sx_exchange` (one tile, one-rank RCCL communicator from `sx_comm_unique_id` / `sx_comm_init`) or
-`sx_exchange_local` (two tiles) → `sx_tile_transform` → `sx_get_physical` - on the reference's `LinearAdvection1D` notebook case.
-`tests/test_gpu_abi_host.py` builds it against `include/scythe_hip.h`, runs it as a fresh process on the MI355X and checks 50
-steps against the oracle (1e-12) and all 2000 steps against the values the reference's notebook prints (1e-11).  Its `case` mode
-creates ANY grid from descriptors (the fields `createHipModelTile` of §2 fills in, written by the test as a small binary file):
-RLZ on uniform rings (node-space path) and on native ragged rings, RL and RZ grids with their equation sets step from the C
-process and every derivative slot matches the oracle to 1e-10, `sx_max_abs` included.  A `ccall` is a
-C call: what this does not cover is Julia's struct layout of `SxGridDesc` / `SxModelDesc` (field order and types are those of
-the header; `tests/test_abi.py` pins the sizes) and the Distributed.jl plumbing around it.

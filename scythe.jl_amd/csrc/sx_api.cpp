@@ -781,13 +781,13 @@ int sx_get_state(sx_handle *h, double *out) {
 
 int sx_set_state(sx_handle *h, const double *in) {
     clear_error();
-    if (h) h->diag_dirty = false;          // the blob carries every variable's coefficients
     if (!h || !in) { set_error("null argument"); return 1; }
     const size_t na = (size_t)h->nbt * h->C, nv = (size_t)h->V * h->N;
     if (in[0] != SX_STATE_MAGIC || in[1] != (double)na || in[2] != (double)nv || in[3] != (h->semi ? 1.0 : 0.0)) {
         set_error("sx_set_state: the blob does not belong to a handle with these dimensions");
         return 1;
     }
+    h->diag_dirty = false;          // the (validated) blob carries every variable's coefficients
     const double *p = in + 4;
     HIPOK(hipMemcpyAsync(h->d_A + (int64_t)h->cell0 * h->C, p, sizeof(double) * na, hipMemcpyHostToDevice, h->stream));
     p += na;
@@ -832,15 +832,15 @@ static int patch_to_device(sx_handle *h, const double *src, double *dst) {
 
 int sx_set_patch_spectral_b(sx_handle *h, const double *shared) {
     clear_error();
-    if (h) h->diag_dirty = false;
     if (!h || !shared) { set_error("null argument"); return 1; }
+    h->diag_dirty = false;          // every variable's B arrives with the (non-null) argument
     return patch_to_device(h, shared, h->d_Bfull);
 }
 
 int sx_set_patch_spectral_a(sx_handle *h, const double *a) {
     clear_error();
-    if (h) h->diag_dirty = false;
     if (!h || !a) { set_error("null argument"); return 1; }
+    h->diag_dirty = false;
     return patch_to_device(h, a, h->d_A);
 }
 
@@ -1193,11 +1193,15 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     const double eq_planes = planes(h->mask_eq_bits, h->mask_eq_val), node_planes = planes(h->mask_node_bits, h->mask_node_val);
     const bool node = h->node_mode && h->node_active;
     const double fin = node ? (double)h->R_in / h->nrings : 1.0;   // fraction of rings on the ring-wise path
+    // node-space units actually transformed and read: cell c of the outer rings combines nodes c .. c + 3 and the first such cell is
+    // R_in / 3, so nodes [R_in / 3, nbt) - 132 of 174 at the bench grid; the nodes below feed the ring-wise inner rings only
+    const double n_units = node ? (double)(h->nbt - h->R_in / MUBAR) : 0.0;
+    const double NGu = n_units * (double)h->uniform_L * h->nz;
     if (k == "k_rl_inverse") b = (N * out_planes + wi * az) * fin;   // write the requested physical planes, read Az
-    else if (k == "k_node_fft") b = (double)h->NG * node_planes + (fusedz ? w * S_tile : wi * (double)h->nbt * h->last_zinv_jobs * h->nz * h->K2);
+    else if (k == "k_node_fft") b = NGu * node_planes + (fusedz ? w * n_units * h->C : wi * n_units * h->last_zinv_jobs * h->nz * h->K2);
     else if (k == "k_phys_hrbl_inner") b = N * fin * (eq_planes + w * (4.0 * V - 3.0));
     else if (k == "k_phys_hrbl" && node)                            // node transforms (read once) + history + outputs
-        b = (double)h->NG * node_planes + N * (1.0 - fin) * w * (4.0 * V - 3.0);
+        b = NGu * node_planes + N * (1.0 - fin) * w * (4.0 * V - 3.0);
     else if (k == "k_zinv") b = w * S_tile * zrows / h->nbt + wi * az;
     else if (k == "k_phys_pointwise" || k == "k_phys_hrbl") {
         // read the requested slots, E_nm1, E_nm2; write E_n, var_np1; the SW sets also write the diagnostic w plane and

@@ -194,7 +194,8 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                  const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, const int *__restrict__ slotmask,
                  int V, int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow,
                  int s_u, int s_r, int s_rr, int s_l, int s_ll, int s_z, int s_zz,
-                 const double *__restrict__ Asrc = nullptr, int64_t Astride = 0, const double *__restrict__ MzT = nullptr, int Zb = 0) {
+                 const double *__restrict__ Asrc = nullptr, int64_t Astride = 0, const double *__restrict__ MzT = nullptr, int Zb = 0,
+                 int unit0 = 0) {
     // NODE: the "rings" are radial NODES (uniform ring tables only): one Az row per unit, no radial combination;
     // the output is the node-space array G that the equation-set kernel combines with the basis weights itself.
     constexpr int L = 1 << LOGL, T = FftCfg<LOGL, HL>::LPT, NK = FftCfg<LOGL, HL>::NK;
@@ -204,7 +205,7 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
     int nslot = 0;
     // grid = (level chunk, ring or node, variable RANK): workgroups are dispatched in blockIdx order, so every unit of the
     // variable with the most requested slots goes first and the variables with few (or no) slots fill the tail of the launch
-    const int ring = blockIdx.y, z0 = blockIdx.x * FZC;
+    const int ring = blockIdx.y + unit0, z0 = blockIdx.x * FZC;      // unit0: first ring / node of the launch
     int v = 0;
     for (int u = 0; u < V; u++) {
         const int cu = __popc(slotmask[u]);
@@ -556,6 +557,7 @@ struct InvTarget {          // where an inverse ring launch writes and which uni
     int n_units, n_phi;     // units launched (rings or nodes), ring count of the phi table
     int64_t N;              // plane size of `out`
     int node_mode;
+    int unit0 = 0;          // first unit of the launch (the node-space launch skips the nodes only the ring-wise inner rings read)
 };
 
 template <int LOGL>
@@ -570,14 +572,15 @@ static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, con
         hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST, AT, HL, SETS>), g, dim3(fft_threads(L, HL)), fft_lds(L, SETS), h->stream, \
                            reinterpret_cast<const AT *>(az), planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart,          \
                            h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],        \
-                           h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6]);                                  \
+                           h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6], nullptr, (int64_t)0, nullptr, 0,  \
+                           tg.unit0);                                                                                                \
     } while (0)
 #define INV_LAUNCH(NODE, ST, AT) INV_LAUNCH_V(NODE, ST, AT, 0, 2)
 #define INV_LAUNCH_FUSED(ST)                                                                                                         \
     hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, true, ST, double, 0, 2, true>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream,  \
                        az, planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart, h->d_tw, tg.phoff, h->d_ph, d_mask, h->V,   \
                        h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4],       \
-                       h->slot[5], h->slot[6], h->d_A + (int64_t)h->cell0 * h->C, h->C, h->d_MzT, h->Zb)
+                       h->slot[5], h->slot[6], h->d_A + (int64_t)h->cell0 * h->C, h->C, h->d_MzT, h->Zb, tg.unit0)
     if (tg.node_mode && fft_fused_zinv(h)) { if (LOGL <= 8) { if (h->f32) INV_LAUNCH_FUSED(float); else INV_LAUNCH_FUSED(double); } }
     else if (h->sp32) { if (tg.node_mode) INV_LAUNCH(true, float, float); else INV_LAUNCH(false, float, float); }     // storage_f32 = 2
     else if (h->f32) { if (tg.node_mode) INV_LAUNCH(true, float, double); else INV_LAUNCH(false, float, double); }
@@ -650,7 +653,10 @@ void launch_node_fft(sx_handle *h) {
         hipMemcpyToSymbol(HIP_SYMBOL(g_fft_dbg), &g_fft_buf, sizeof(g_fft_buf));
     }
 #endif
-    InvTarget tg{h->d_G, h->d_nphi, h->d_nkmax, h->d_npstart, h->d_nphoff, h->nbt, h->nbt, h->NG, 1};
+    // cell c of the node-space rings combines nodes c .. c + 3 and the first such cell is R_in / 3: the nodes below it feed the
+    // ring-wise inner rings only (through Az), their node-space transforms would never be read (42 of 174 at the bench grid)
+    const int j0 = h->R_in / MUBAR;
+    InvTarget tg{h->d_G, h->d_nphi, h->d_nkmax, h->d_npstart, h->d_nphoff, h->nbt - j0, h->nbt, h->NG, 1, j0};
     launch_inv_any(h, h->d_mask_node, tg);
     timer_end(h);
 }

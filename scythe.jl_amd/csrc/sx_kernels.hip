@@ -1758,7 +1758,8 @@ void launch_zinv(sx_handle *h, bool full) {
         h->last_zinv_rows = rows;
         if (rows == 0) { timer_end(h); return; }
         static const int ct_env = getenv("SX_ZINV_CT") ? atoi(getenv("SX_ZINV_CT")) : 0;      // A/B: column tiles per wave at 128 levels
-        const int ct = h->nz == 128 ? (ct_env > 0 ? ct_env : 2) : (h->nz == 64 && ct_env == 2 ? 2 : 1);
+        // only CT = 1, 2, 4 are instantiated at 128 levels (1, 2 at 64): any other request takes the default, never a grid sized for a kernel that is not launched
+        const int ct = h->nz == 128 ? ((ct_env == 1 || ct_env == 4) ? ct_env : 2) : (h->nz == 64 && ct_env == 2 ? 2 : 1);
         dim3 g((h->K2 + 64 * ct - 1) / (64 * ct), njobs, rows);
         const ColJob *jobs = full ? h->d_jobs_zinv_full : h->d_jobs_zinv_eq;
         const int64_t azrow = (int64_t)h->V * 3 * h->nz * h->K2;

@@ -433,9 +433,10 @@ class ModelRun:
         nb = self.layout.b_rDim
         parts = []
         for t, g in zip(self.tile_ids, self.tiles):
-            a = g.patchSpectral.reshape(-1, nb, g.V, order="F")             # [z-mode x block, node, var], node fastest
+            # reference layout of one variable's column: s = (z-mode * n_blocks + block) * b_rDim + node, the node FASTEST
+            a = g.patchSpectral.reshape(nb, -1, g.V, order="F")             # [node, z-mode x block, var]
             c0 = self.layout.cell0[t]
-            parts.append((c0, np.ascontiguousarray(a[:, c0:c0 + self.layout.owned_rows(t), :])))
+            parts.append((c0, np.ascontiguousarray(a[c0:c0 + self.layout.owned_rows(t)])))
         if self.use_dist:
             import torch.distributed as dist
             box = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
@@ -443,9 +444,9 @@ class ModelRun:
             if dist.get_rank() != 0:
                 return None
             parts = [p for ps in box for p in ps]
-        out = np.zeros((parts[0][1].shape[0], nb, parts[0][1].shape[2]))
+        out = np.zeros((nb, parts[0][1].shape[1], parts[0][1].shape[2]))
         for c0, rows in parts:
-            out[:, c0:c0 + rows.shape[1], :] = rows
+            out[c0:c0 + rows.shape[0]] = rows
         return out.reshape(-1, out.shape[2], order="F")
 
     def synchronize(self):

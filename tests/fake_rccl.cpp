@@ -14,7 +14,9 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 #include <fcntl.h>
@@ -38,14 +40,29 @@ struct Comm {
     unsigned char *base = nullptr;
     Header *hdr = nullptr;
     unsigned char *slot(int src, int dst) { return base + 4096 + ((size_t)src * n + dst) * SLOT_BYTES; }
-    void barrier() {
+    // returns false when a peer has not arrived after SX_FAKE_RCCL_TIMEOUT seconds (default 120): a rank that died must not leave
+    // the others spinning here, holding the GPU, for the rest of the session
+    bool barrier() {
+        static const double limit = getenv("SX_FAKE_RCCL_TIMEOUT") ? atof(getenv("SX_FAKE_RCCL_TIMEOUT")) : 120.0;
         const int gen = hdr->generation.load();
         if (hdr->arrived.fetch_add(1) + 1 == n) {
             hdr->arrived.store(0);
             hdr->generation.fetch_add(1);
-        } else {
-            while (hdr->generation.load() == gen) sched_yield();
+            return true;
         }
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (long spins = 0; hdr->generation.load() == gen; spins++) {
+            sched_yield();
+            if ((spins & 1023) == 1023) {
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > limit) {
+                    fprintf(stderr, "fake_rccl: rank %d waited %.0f s at a barrier for its peers - giving up\n", me, limit);
+                    return false;
+                }
+            }
+        }
+        return true;
     }
 };
 
@@ -63,10 +80,10 @@ int run_group() {
             if (o.bytes > SLOT_BYTES) { fprintf(stderr, "fake_rccl: message of %zu bytes exceeds the mailbox\n", o.bytes); return 2; }
             if (o.bytes && hipMemcpy(c->slot(c->me, o.peer), o.buf, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
         }
-    c->barrier();
+    if (!c->barrier()) { g_ops.clear(); return 4; }
     for (auto &o : g_ops)
         if (o.kind == 1 && o.bytes && hipMemcpy(o.buf, c->slot(o.peer, c->me), o.bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
-    c->barrier();
+    if (!c->barrier()) { g_ops.clear(); return 4; }
     g_ops.clear();
     return 0;
 }
@@ -95,7 +112,7 @@ int ncclCommInitRank(void **comm, int n, ncclUniqueId id, int rank) {
     close(fd);
     if (c->base == MAP_FAILED) return 3;
     c->hdr = reinterpret_cast<Header *>(c->base);        // a fresh segment is zero-filled: arrived = generation = 0
-    c->barrier();                                        // collective, like the real call
+    if (!c->barrier()) return 4;                         // collective, like the real call
     *comm = c;
     return 0;
 }
@@ -109,7 +126,7 @@ int ncclCommDestroy(void *comm) {
     return 0;
 }
 
-const char *ncclGetErrorString(int rc) { return rc == 0 ? "ok" : rc == 1 ? "fake_rccl: HIP call failed" : rc == 2 ? "fake_rccl: message too large" : "fake_rccl: shared memory"; }
+const char *ncclGetErrorString(int rc) { return rc == 0 ? "ok" : rc == 1 ? "fake_rccl: HIP call failed" : rc == 2 ? "fake_rccl: message too large" : rc == 4 ? "fake_rccl: a peer did not reach the barrier in time" : "fake_rccl: shared memory"; }
 
 int ncclGroupStart() { g_depth++; return 0; }
 int ncclGroupEnd() { return --g_depth == 0 ? run_group() : 0; }
@@ -128,10 +145,10 @@ int ncclAllGather(const void *send, void *recv, size_t count, int dtype, void *c
     const size_t bytes = count * sizeof(double);
     if (hipStreamSynchronize(s) != hipSuccess) return 1;
     if (bytes && hipMemcpy(c->slot(c->me, c->me), send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 1;
-    c->barrier();
+    if (!c->barrier()) return 4;
     for (int r = 0; r < c->n; r++)
         if (bytes && hipMemcpy((char *)recv + (size_t)r * bytes, c->slot(r, r), bytes, hipMemcpyHostToDevice) != hipSuccess) return 1;
-    c->barrier();
+    if (!c->barrier()) return 4;
     return 0;
 }
 

@@ -14,6 +14,22 @@ from tests import cases
 pytestmark = pytest.mark.gpu
 
 
+
+def _join_all(procs, seconds):
+    """Wait for every rank, then end exactly the ranks started here that are still alive (a dead or hung rank must not leave its
+    peers spinning in a barrier with the GPU in their hands), and only then look at the exit codes."""
+    for p in procs:
+        p.join(seconds)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            p.join(20)
+            if p.is_alive():
+                p.kill()
+                p.join(10)
+    assert [p.exitcode for p in procs] == [0] * len(procs)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -61,9 +77,7 @@ def test_two_ranks_one_gpu(exchange):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, exchange, q)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+    _join_all(procs, 300)
     res = dict(q.get(timeout=5) for _ in range(2))
     assert max(res.values()) < 1e-10
 
@@ -78,9 +92,7 @@ def test_four_ranks_one_gpu_uneven_tiles_node_space_path():
     procs = [ctx.Process(target=_worker, args=(r, 4, port, "a2a", q, kw)) for r in range(4)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0
+    _join_all(procs, 600)
     res = dict(q.get(timeout=5) for _ in range(4))
     assert max(res.values()) < 1e-10
 
@@ -249,9 +261,7 @@ def test_in_library_exchange_multi_rank_through_a_stand_in_transport(tmp_path, e
     procs = [ctx.Process(target=_fake_worker, args=(r, world, lib, uid, exchange, case_name, case_kw, q)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0
+    _join_all(procs, 600)
     res = dict(q.get(timeout=5) for _ in range(world))
     assert sorted(res) == list(range(world))
     assert max(res.values()) < 1e-10, res
@@ -332,13 +342,7 @@ def test_drawn_configurations_with_ranks_in_separate_processes(tmp_path, index):
     procs = [ctx.Process(target=_fake_worker, args=(r, world, lib, uid, exchange, "fuzz", {"seed": 4711, "index": index}, q)) for r in range(world)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(240)
-    for p in procs:
-        if p.is_alive():                 # exactly the processes started above
-            p.terminate()
-            p.join(20)
-    assert [p.exitcode for p in procs] == [0] * world
+    _join_all(procs, 240)
     res = dict(q.get(timeout=5) for _ in range(world))
     print("\n%s %s cells=%d ranks=%d %s: %s" % (case["grid"]["geometry"], case["eq"], case["grid"]["num_cells"], world, exchange, res))
     assert max(res.values()) < 1e-8, res

@@ -227,6 +227,33 @@ def test_interface_only_solve_on_tiles_matches_single_patch_oracle(maker, kw, nt
     assert _run(case, 4, num_tiles=ntiles, exchange="iface", impl=impl) < TOL
 
 
+@pytest.mark.parametrize("maker,kw,ntiles,exchange", [(cases.rlz_hrbl, {"num_cells": 24, "zDim": 32, "ring_L": 16}, 3, "iface"),
+                                                      (cases.rlz_hrbl, {"num_cells": 9, "zDim": 10}, 2, "a2a"),          # native rings
+                                                      (cases.rz_semiimplicit, {"num_cells": 21}, 3, "iface"),
+                                                      (cases.rl_slab, {"num_cells": 20}, 2, "iface")])
+def test_patch_spectral_assembled_from_tiles_is_the_one_patch_array(maker, kw, ntiles, exchange):
+    """ModelRun.patch_spectral() (what spectral_out_<t>.csv is written from, src/semiimplicit.jl:288-293) in the transposed and
+    interface-only modes, where no tile holds the whole patch: the array assembled from the tiles' owned rows must be the
+    one-tile run's patchSpectral, and fed back through set_patch_spectral_a + tileTransform! it must reproduce the tiles'
+    own physical fields.  Grids with more than one (z-mode, wavenumber) block per variable - on the 1-D grid of the
+    notebook case the node axis cannot be confused with anything."""
+    import scythe_jl_amd as S
+    case = maker(**kw)
+    multi, one = cases.HipModel(case, num_tiles=ntiles, exchange=exchange), cases.HipModel(case)
+    for _ in range(3):
+        multi.step()
+        one.step()
+    a = multi.run.patch_spectral()
+    b = one.run.tiles[0].patchSpectral
+    assert a.shape == b.shape
+    assert cases.rel_err(a, b) < TOL
+    phys = multi.physical()
+    g1 = one.run.tiles[0]
+    g1.set_patch_spectral_a(a)
+    g1.tileTransform_()
+    assert cases.rel_err_per_var(g1.physical, phys) < TOL
+
+
 def test_interface_only_solve_refuses_tiles_that_are_too_small():
     import scythe_jl_amd as S
     case = cases.rl_slab(num_cells=9)
