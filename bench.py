@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 HBM_ACHIEVABLE_GBS = 6300.0   # same guide: 6.29 TB/s measured for a float4 copy (79 % of spec)
-PROFILE_ROUND = "r03"     # profiles/<round>/pmc_traffic_<workload>.json: the PMC passes of the current build
+PROFILE_ROUND = "r04"     # profiles/<round>/pmc_traffic_<workload>.json: the PMC passes of the current build
 
 WORKLOADS = {
     # name: (num_cells, ring_L, zDim)
@@ -40,6 +40,16 @@ WORKLOADS = {
     # SURVEY.md 8(d) config 5 (use with --storage f32): 341 cells -> 1023 rings x 512 x 128
     "rlz_1023x512x128": (341, 512, 128),
 }
+# BASELINE.json configs 2 and 3 (bench_configs.py; one GPU, not the headline): reported under "other_configs" of the headline
+# line, or as the line's own workload with --workload
+OTHER_WORKLOADS = {
+    "rl_cha_bell2024": "config2_literal",      # models/cha_bell2024/Oneway_ShallowWater_Slab.jl:1-40, 100 cells, native rings
+    "rz_513x128_semi": "config3_rz",           # RZ 513 x 128, Chebyshev vertical + semiimplicit_adjustment (src/semiimplicit.jl:521-597)
+}
+PARITY_CLAIM = ("fields within 1e-10 of the CPU oracle: the A coefficients and the VALUE slot of every variable, at this grid's full size over "
+                "25 steps (tests/test_gpu_configs.py::test_config4_full_size_25_steps_against_the_c_oracle); the derivative slots "
+                "(d/dr .. d2/dz2) are held to 'no less accurate than the fp64 oracle against an extended-precision evaluation of the same "
+                "coefficients' and to 10x the spread between two fp64 oracles - two correct fp64 runs differ there by k^2 / N^4 times the last bit")
 TS_OF = {"rlz_1023x512x128": 0.02}     # 128 levels: 0.3 m end spacing of the Chebyshev column
 VARS6 = {"h": 1, "u": 2, "v": 3, "ub": 4, "vb": 5, "wb": 6}
 BCL6 = {"h": "R1T1", "u": "R1T0", "v": "R1T0", "ub": "R1T0", "vb": "R1T0", "wb": "R1T1"}
@@ -120,15 +130,18 @@ def cpu_baseline(workload, sample_cells, steps):
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher in front: start `torch.distributed.run` with N ranks of this very
     command line as a child process (never exec: this is called before torch or HIP are imported, and the parent never
-    touches the GPU), pass the ranks' stdout / stderr through and return the launcher's exit status.
+    touches the GPU), pass the ranks' stderr through, relay ONE contract line and return the launcher's exit status.
     Watchdog: the in-library RCCL exchange has never run with more than one rank on real hardware (no multi-GPU node was
     available to the builder).  If the job has not finished after SX_BENCH_TIMEOUT seconds (default 420) the launcher's own
     process group - exactly the processes started here - is killed and the job is run ONCE more with the exchange done by
-    torch.distributed (`--exchange-impl torch`, recorded in config.exchange_impl); the same happens if the job exits with a
-    non-zero status (its output has already gone to stderr).  A second failure is the failure."""
+    torch.distributed (`--exchange-impl torch`); the same happens if the job exits with a non-zero status.  The record shows it:
+    only the FINAL attempt's JSON line goes to stdout, and it carries the first attempt's outcome (exit status or timeout, the
+    tail of its stderr, its own JSON line if it printed one) in config.lib_attempt and in config.exchange_impl.  A second
+    failure is the failure."""
     import signal
     import socket
     import subprocess
+    import threading
 
     def attempt(extra):
         s = socket.socket()
@@ -139,9 +152,23 @@ def spawn_ranks(n):
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
         env = dict(os.environ)
         env.setdefault("OMP_NUM_THREADS", "1")       # what the launcher would set anyway, without its warning
-        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True)
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        out_lines, err_tail = [], []
+
+        def pump(stream, keep, forward):
+            for line in stream:
+                keep.append(line)
+                if forward is not None:
+                    forward.write(line)
+                    forward.flush()
+                    del keep[:-40]
+
+        th = [threading.Thread(target=pump, args=(proc.stdout, out_lines, None), daemon=True),
+              threading.Thread(target=pump, args=(proc.stderr, err_tail, sys.stderr), daemon=True)]
+        for t in th:
+            t.start()
         try:
-            return proc.wait(timeout=float(os.environ.get("SX_BENCH_TIMEOUT", "420")))
+            rc = proc.wait(timeout=float(os.environ.get("SX_BENCH_TIMEOUT", "420")))
         except subprocess.TimeoutExpired:
             for sig in (signal.SIGTERM, signal.SIGKILL):
                 try:
@@ -153,14 +180,110 @@ def spawn_ranks(n):
                     break
                 except subprocess.TimeoutExpired:
                     continue
-            return None
+            rc = None
+        for t in th:
+            t.join(5)
+        line = None
+        for ln in out_lines:                             # the contract line: the last stdout line that parses as a JSON object with "metric"
+            try:
+                d = json.loads(ln)
+                if isinstance(d, dict) and "metric" in d:
+                    line = d
+            except ValueError:
+                pass
+        return rc, line, "".join(err_tail)[-1500:]
 
-    rc = attempt([])
+    rc, line, err = attempt([])
+    first = None
     if rc != 0 and "--exchange-impl" not in sys.argv[1:]:
-        print("bench.py: the %d-rank job %s; once more with --exchange-impl torch" % (n, "did not finish in time" if rc is None else "exited with status %d" % rc),
-              file=sys.stderr, flush=True)
-        rc = attempt(["--exchange-impl", "torch"])
+        first = {"outcome": "timed out" if rc is None else "exited with status %d" % rc, "stderr_tail": err, "json_line": line}
+        print("bench.py: the %d-rank job %s; once more with --exchange-impl torch" % (n, first["outcome"]), file=sys.stderr, flush=True)
+        rc, line, err = attempt(["--exchange-impl", "torch"])
+    if line is not None:
+        if first is not None:
+            line.setdefault("config", {})["lib_attempt"] = first
+            line["config"]["exchange_impl"] = "torch (retry: the run with the in-library exchange %s)" % first["outcome"]
+        print(json.dumps(line), flush=True)
     return 124 if rc is None else rc
+
+
+def kernel_table(tile, per_step_ms, launches_per_step, pmc):
+    """Per-kernel roofline rows: algorithmic bytes of one launch (sx_kernel_bytes: SURVEY.md 8(d)'s accounting, every array a launch
+    touches counted once), the hipEvent average of one launch, GB/s and the fraction of the 8 TB/s HBM peak; with PMC passes of
+    this very library build (sha256 match) also the measured HBM bytes per launch."""
+    rows = {}
+    for k in sorted(per_step_ms):
+        n = max(launches_per_step.get(k, 1.0), 1e-9)
+        ms = per_step_ms[k] / n
+        b = tile.kernel_bytes(k)
+        row = {"ms_per_launch": ms, "launches_per_step": n, "algorithmic_bytes": b,
+               "achieved_GBs": (b / (ms * 1e-3) / 1e9) if ms > 0 and b > 0 else None,
+               "frac": (b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 and b > 0 else None}
+        if pmc and k in pmc:
+            row["pmc_bytes"] = pmc[k]["hbm_bytes"]
+            row["pmc_GBs"] = pmc[k]["hbm_bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else None
+        rows[k] = row
+    return rows
+
+
+def load_pmc(S, workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this workload (FETCH_SIZE / WRITE_SIZE, collected and corrected
+    as profiles/summarize_pmc.py documents) - only if those passes ran with the very library loaded now: a stale number is worse than none."""
+    tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic_%s.json" % workload)
+    if not os.path.exists(tfile):
+        return None
+    import hashlib
+    pmc = json.load(open(tfile))
+    if pmc.get("_meta", {}).get("lib_sha256") != hashlib.sha256(open(S.LIB_PATH, "rb").read()).hexdigest():
+        return None
+    return pmc
+
+
+def time_other_config(S, torch, dev, name, steps, warmup, graph=None):
+    """BASELINE.json config 2 / 3 on this GPU: `warmup` steps with an event pair around every kernel (the per-kernel table), then
+    `steps` timed steps with no event on the stream (ms_per_step).  Returns the dictionary reported under other_configs."""
+    import bench_configs as BC
+    case = getattr(BC, OTHER_WORKLOADS[name])()
+    mp = BC.model_parameters(S, case)
+    run = S.ModelRun(mp, num_tiles=1, device=dev)
+    tile = run.tiles[0]
+    pts = S.getGridpoints(tile)
+    run.set_initial_conditions([case["ic"](pts.reshape(len(pts), -1))])
+    for _ in range(20):                               # clocks, caches, first-launch costs
+        run.step()
+    torch.cuda.synchronize()
+    tile.enable_timers(True)
+    tile.reset_timers()
+    for _ in range(warmup):
+        run.step()
+    torch.cuda.synchronize()
+    tm = tile.timers()
+    tile.enable_timers(False)
+    per_step = {k: v[0] / max(warmup, 1) for k, v in tm.items() if v[1] > 0}
+    launches = {k: v[1] / max(warmup, 1) for k, v in tm.items() if v[1] > 0}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    rows = kernel_table(tile, per_step, launches, load_pmc(S, name))
+    dom = max(per_step.items(), key=lambda kv: kv[1])[0] if per_step else None
+    d = tile.dims
+    # SURVEY.md 8(d)'s fixed byte model of a step: B_step = 8 V [N (2 D + 5) + 4 S]
+    b_step = 8.0 * d.n_vars * (d.n_points * (2 * d.n_derivs + 5) + 4 * d.s_patch)
+    out = {"workload": {"rl_cha_bell2024": "RL two-layer shallow-water slab, models/cha_bell2024/Oneway_ShallowWater_Slab.jl verbatim: 100 cells -> 300 native "
+                                           "ragged rings (4 + 4 ri points, kmax = ri), %d points x 6 vars, 5 derivative slots, fp64" % d.n_points,
+                        "rz_513x128_semi": "RZ %d x %d (radius x Chebyshev levels, b_zDim = zDim), 5 vars, LinearAcousticRZ + semi-implicit adjustment "
+                                           "(src/semiimplicit.jl:521-597), fp64" % (d.rDim, d.zDim)}[name],
+           "steps_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "steps": steps, "nan": bool(tile.check_nan()),
+           "survey_bytes_per_step": b_step, "survey_model_frac_of_hbm_peak": b_step / dt / 1e9 / HBM_PEAK_GBS,
+           "kernel_ms_per_step_sum": sum(per_step.values()),
+           "roofline": ({"bound": "hbm", "kernel": dom, "achieved": rows[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": rows[dom]["frac"], "traffic": rows[dom].get("pmc_bytes"), "avg_launch_ms": rows[dom]["ms_per_launch"],
+                         "algorithmic_bytes_per_launch": rows[dom]["algorithmic_bytes"]} if dom else None),
+           "kernels_roofline": rows}
+    run.close()
+    return out
 
 
 def main():
@@ -168,7 +291,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="rlz_513x256x64", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="rlz_513x256x64", choices=sorted(WORKLOADS) + sorted(OTHER_WORKLOADS))
     ap.add_argument("--exchange", default="iface", choices=["iface", "a2a", "gather"],
                     help="multi-GPU patch solve: interface-only solve (default: tile-local solves, two all-to-alls of 10 rows per tile; "
                          "falls back to a2a when a tile has fewer than 9 cells), transposed all-to-all, or the reference's halo + gather protocol")
@@ -184,9 +307,14 @@ def main():
     ap.add_argument("--exchange-impl", default="lib", choices=["lib", "torch"],
                     help="N > 1: 'lib' = ncclSend/Recv/AllGather issued inside libscythe_hip.so on the tile's stream (sx_exchange), "
                          "'torch' = torch.distributed collectives on device tensors (always used with --backend gloo)")
+    ap.add_argument("--schedule", default="overlap", choices=["overlap", "serial"],
+                    help="N = 1 headline: 'overlap' (default) times `value` with the inner-ring chain on a second stream (SX_OVERLAP=1: the same "
+                         "kernels and bit-identical fields, the latency-bound FFT kernels fill in under the bandwidth-bound equation-set kernels) "
+                         "and takes `roofline` from a separate serial pass of the same length; 'serial' times `value` on one stream")
     ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip the 2-step comparison of the two exchange implementations")
     ap.add_argument("--no-native", action="store_true", help="skip the native-ragged-ring run reported as native_equivalent")
-    ap.add_argument("--no-kernel-timers", action="store_true", help="diagnostic: no hipEvent pair per kernel in the timed loop (no roofline object)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE.json configs 2 and 3 (other_configs)")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="diagnostic: no hipEvent pair per kernel anywhere (no roofline object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=0, help="0 = time the C port on the full grid (default); n > 0 = extrapolate from n cells")
     ap.add_argument("--cpu-steps", type=int, default=3)
@@ -209,6 +337,22 @@ def main():
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    if args.workload in OTHER_WORKLOADS:
+        # configs 2 / 3 as the line's own workload (one GPU): value = that configuration's steps/s, labelled as not the headline
+        if world != 1:
+            raise SystemExit("bench.py: --workload %s is a one-GPU configuration" % args.workload)
+        r = time_other_config(S, torch, dev, args.workload, args.steps, max(args.warmup, 1))
+        out = {"metric": "model steps/sec, %s (BASELINE.json config, not the headline configuration)" % args.workload,
+               "value": None if r["nan"] else r["steps_per_s"], "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic", "config": {"workload": r["workload"], "nan": r["nan"], "survey_bytes_per_step": r["survey_bytes_per_step"],
+                                                 "survey_model_frac_of_hbm_peak": r["survey_model_frac_of_hbm_peak"]},
+               "roofline": r["roofline"], "kernels_roofline": r["kernels_roofline"]}
+        print(json.dumps(out), flush=True)
+        raise SystemExit(3 if r["nan"] else 0)
+
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -230,13 +374,24 @@ def main():
         # takes rows away): decided from the tile table, i.e. identically on every rank
         if min(S.PatchLayout(gp, world, split=args.tile_split).ncells) < 9:
             args.exchange = "a2a"
-    dev = torch.device("cuda", local_rank)
     selfcheck = None
 
-    def make_run(which):
-        r = S.ModelRun(mp, num_tiles=world, rank=rank, device=dev, use_dist=world > 1, exchange=args.exchange, split=args.tile_split,
-                       impl=which)
-        r.set_initial_conditions([initial_condition(S.getGridpoints(r.tiles[0]))])
+    def make_run(which, overlap=False):
+        # SX_OVERLAP is read by sx_create: the handle keeps its schedule for life
+        if overlap:
+            os.environ["SX_OVERLAP"] = "1"
+        r = None
+        try:
+            r = S.ModelRun(mp, num_tiles=world, rank=rank, device=dev, use_dist=world > 1, exchange=args.exchange, split=args.tile_split,
+                           impl=which)
+            r.set_initial_conditions([initial_condition(S.getGridpoints(r.tiles[0]))])
+        except Exception:
+            if r is not None:
+                r.close()                    # a half-built run must not keep its tiles (and their device memory) alive
+            raise
+        finally:
+            if overlap:
+                os.environ.pop("SX_OVERLAP", None)
         return r
 
     if world > 1 and impl == "lib":
@@ -280,6 +435,17 @@ def main():
     else:
         run = make_run(impl if world > 1 else "torch")
     tile = run.tiles[0]
+    headline = (world == 1 and args.workload == "rlz_513x256x64")
+    # N = 1 headline: the SAME work on two streams (SX_OVERLAP=1: inner-ring chain k_rl_inverse -> k_phys_hrbl_inner beside
+    # k_node_fft -> k_phys_hrbl; bit-identical fields, tests/test_gpu_configs.py::test_config4_full_size_two_stream_modes_are_bit_identical) is the faster schedule and
+    # what `value` is timed with; the dominant kernel then shares the chip, so its event-timed duration (the roofline measurement) comes
+    # from a serial pass of the same K steps on `run`, after the timed region.  --schedule serial times `value` on `run` itself.
+    run_ov = None
+    if world == 1 and args.schedule == "overlap" and args.storage == "f64":
+        run_ov = make_run("torch", overlap=True)
+        if not (run_ov.tiles[0].dims.n_points == tile.dims.n_points):
+            run_ov.close()
+            run_ov = None
 
     # The same model on Springsteel's NATIVE ragged rings (SURVEY.md 8(d) "native-equivalent shape": 85 cells -> 255 rings of
     # 4 + 4 ri points, 131,580 horizontal points x 64 levels): the layout a drop-in must run; its azimuthal transforms are dense
@@ -292,7 +458,7 @@ def main():
     # After this run the GPU is in its working state
     # when the W warm-up steps begin.  `--no-native` skips it.
     native, runn = None, None
-    if world == 1 and rank == 0 and args.workload == "rlz_513x256x64" and not args.no_native:
+    if headline and rank == 0 and not args.no_native:
         try:
             kwn, _ = grid_kwargs(args.workload)
             kwn["num_cells"] = 85
@@ -321,9 +487,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up, with every kernel timed (rank 0): finds the dominant kernel and gives the per-kernel table.  An event pair
-    # costs ~8 us on the stream, 16 pairs per step were 6 % of the step - so the TIMED region below carries the pair of the
-    # dominant kernel only (the roofline object needs that one, measured live over the timed region).
+    # Warm-up of `run` (serial schedule), with every kernel timed (rank 0): finds the dominant kernel and gives the per-kernel table.
+    # An event pair costs ~4 us on the stream, 16 pairs per step were 6 % of the step - so a TIMED region carries the pair of the
+    # dominant kernel only (the roofline object needs that one, measured live over K steps), or none at all (the overlapped schedule).
     use_timers = (rank == 0 and not args.no_kernel_timers)
     tile.enable_timers(use_timers)
     tile.reset_timers()
@@ -331,23 +497,49 @@ def main():
         run.step()
     barrier()
     warm = tile.timers() if use_timers else {}
-    all_kernels = {k: v[0] / max(args.warmup, 1) for k, v in warm.items()}
-    dominant = max(warm.items(), key=lambda kv: kv[1][0])[0] if warm and args.warmup > 0 else None
+    all_kernels = {k: v[0] / max(args.warmup, 1) for k, v in warm.items() if v[1] > 0}
+    launches = {k: v[1] / max(args.warmup, 1) for k, v in warm.items() if v[1] > 0}
+    dominant = max(all_kernels.items(), key=lambda kv: kv[1])[0] if all_kernels and args.warmup > 0 else None
     tile.timer_only(dominant)
     tile.reset_timers()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    serial = None
+    if run_ov is not None:
+        # ---- THE timed region: exactly K steps of the two-stream schedule, no event on any stream
+        for _ in range(args.warmup):
+            run_ov.step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_ov.step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        nan = run_ov.tiles[0].check_nan()
+        # ---- the serial pass: the same K steps on one stream with the dominant kernel's event pair -> roofline
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run.step()
+        barrier()
+        el_serial = time.perf_counter() - t0
+        serial = {"steps_per_s": args.steps / el_serial, "ms_per_step": 1e3 * el_serial / args.steps, "steps": args.steps,
+                  "note": "one stream, the dominant kernel's hipEvent pair on it: the pass `roofline` is measured in"}
+        nan = bool(nan) or bool(tile.check_nan())
+    else:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run.step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        nan = tile.check_nan()
     timers = {k: v for k, v in tile.timers().items() if v[1] > 0}
     if runn is not None:
         runn.close()
     if preheat is not None:
         preheat.close()
+    if run_ov is not None:
+        run_ov.close()
     tile.enable_timers(False)
     tile.timer_only(None)
-    nan = tile.check_nan()
 
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -364,17 +556,13 @@ def main():
         bytes_per_launch = tile.kernel_bytes(name) if calls else 0.0
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         nc, _, nz = WORKLOADS[args.workload]
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (FETCH_SIZE / WRITE_SIZE,
-        # collected and corrected as profiles/summarize_pmc.py documents) - but only if those passes ran with the very
-        # library loaded now (sha256 recorded by summarize_pmc.py): a stale number is worse than none
-        traffic, step_traffic = None, None
-        tfile = os.path.join(ROOT, "profiles", PROFILE_ROUND, "pmc_traffic_%s.json" % args.workload)
-        if world == 1 and args.storage == "f64" and os.path.exists(tfile):
-            import hashlib
-            pmc = json.load(open(tfile))
-            if pmc.get("_meta", {}).get("lib_sha256") == hashlib.sha256(open(S.LIB_PATH, "rb").read()).hexdigest():
-                traffic = pmc.get(name, {}).get("hbm_bytes")
-                step_traffic = sum(pmc[k]["hbm_bytes"] * (warm[k][1] / max(args.warmup, 1)) for k in warm if k in pmc)
+        pmc = load_pmc(S, args.workload) if (world == 1 and args.storage == "f64") else None
+        traffic = pmc.get(name, {}).get("hbm_bytes") if pmc else None
+        step_traffic = sum(pmc[k]["hbm_bytes"] * launches.get(k, 0.0) for k in all_kernels if k in pmc) if pmc else None
+        rows = kernel_table(tile, all_kernels, launches, pmc) if all_kernels else {}
+        if name in rows:                    # the dominant kernel's row from the timed pass (K steps), not from the warm-up
+            rows[name].update({"ms_per_launch": avg_ms, "achieved_GBs": achieved, "frac": achieved / HBM_PEAK_GBS,
+                               "pmc_GBs": (traffic / (avg_ms * 1e-3) / 1e9) if traffic and avg_ms > 0 else None, "timed_over": "%d steps" % args.steps})
         out = {
             "metric": ("model steps/sec, RLZ 512x256x64 shallow-water" if args.workload == "rlz_513x256x64"
                        else "model steps/sec, %s shallow-water (not the headline configuration)" % args.workload),
@@ -395,25 +583,34 @@ def main():
                                    % (3 * nc, L, nz, L // 2 - 1, int(tile.dims.b_zDim)),
                        "num_cells": nc, "tiles": world, "tile_cells": list(run.layout.ncells), "exchange": run.exchange_kind,
                        "exchange_impl": (impl if world > 1 else "none"), "exchange_selfcheck_max_rel_diff": selfcheck,
+                       "schedule": ("two streams (SX_OVERLAP=1): the inner-ring chain beside the node-space chain; the same kernels, "
+                                    "bit-identical fields" if run_ov is not None else "one stream"),
                        # what ran on the device right before the W warm-up steps (from an idle GPU the first ~25 steps of
                        # any run are up to 18 % slow)
                        "device_busy_before_warmup": ("native_equivalent run" if native is not None else
-                                                     "self-check's torch.distributed run, 100 steps" if preheat is not None else "nothing (cold start)"), "ts": TS_OF.get(args.workload, TS), "nan": bool(nan)},
+                                                     "self-check's torch.distributed run, 100 steps" if preheat is not None else "nothing (cold start)"),
+                       "ts": TS_OF.get(args.workload, TS), "nan": bool(nan),
+                       "parity": PARITY_CLAIM if args.storage == "f64" else "declared tolerance of the fp32-storage mode: values 1e-6, derivative slots 5e-5 (DESIGN.md 3)"},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "measured_in": ("the serial pass (serial_schedule), %d steps" % args.steps if serial is not None else "the timed region"),
                          "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          # whole step: PMC bytes of every kernel of a step / step time (null without matching PMC passes)
                          "step_traffic": step_traffic,
                          "step_achieved": (step_traffic / (ms_per_step * 1e-3) / 1e9) if step_traffic else None,
                          "step_frac": (step_traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if step_traffic else None},
-            # every kernel, from the warm-up steps (all event pairs on); the dominant one again from the timed region
+            # every kernel of a step: algorithmic bytes, PMC bytes (matching build only), launch time, fraction of the HBM peak - from the
+            # warm-up steps of the serial schedule (all event pairs on); the dominant kernel's row from its K timed steps
+            "kernels_roofline": rows,
             "kernels_ms_per_step": {k: v for k, v in sorted(all_kernels.items())},
             "dominant_kernel_ms_timed_region": {k: v[0] / args.steps for k, v in sorted(timers.items())},
         }
+        if serial is not None:
+            out["serial_schedule"] = serial
         if native is not None:
             out["native_equivalent"] = native
-        if world == 1 and args.workload == "rlz_513x256x64" and not args.no_native and not nan:
+        if headline and not args.no_native and not nan:
             # NOT the headline: the same model with SX_DEFER_DIAG=1 - the diagnostic variable w (written by the equation set
             # before it is read, so its spline coefficients are consumed by output only) skips the forward transform and the
             # solve inside the step and is brought up to date when something reads A or B; every observable is bit-identical
@@ -439,6 +636,14 @@ def main():
             except Exception as e:
                 os.environ.pop("SX_DEFER_DIAG", None)
                 out["deferred_diagnostic"] = {"steps_per_s": None, "error": repr(e)[:200]}
+        if headline and not args.no_other_configs:
+            # BASELINE.json configs 2 and 3 ("1 MI355X" configurations; parity: tests/test_gpu_configs.py) - reported, never `value`
+            out["other_configs"] = {}
+            for oname in sorted(OTHER_WORKLOADS):
+                try:
+                    out["other_configs"][oname] = time_other_config(S, torch, dev, oname, 200 if args.steps >= 20 else max(5, args.steps), 20)
+                except Exception as e:
+                    out["other_configs"][oname] = {"steps_per_s": None, "error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample_cells, args.cpu_steps)

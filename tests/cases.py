@@ -277,31 +277,7 @@ def rel_err_per_var(a, b):
 
 
 # ----------------------------------------------------------------------------- BASELINE.json configs at full size
-def config2_literal(twoway=False):
-    """configs[1]: models/cha_bell2024/Oneway_ShallowWater_Slab.jl verbatim (100 cells, native ragged rings,
-    N = 181,800) with the notebook's Rankine vortex + wave-2 perturbation (Cha_Bell_WCD2024_initialization.ipynb)."""
-    def ic(p):
-        r, l = p[:, 0], p[:, 1]
-        Rmax, Vmax, eps, f = 50000.0, 50.0, 5000.0, 5.0e-5
-        V0 = Vmax / Rmax
-        zeta = 2.0 * V0
-        vbar = np.where(r < Rmax, V0 * r, Rmax * Rmax * V0 / r)
-        # gradient-balanced height dh/dr = (f v + v^2 / r) / g in closed form (pointwise, so tiles can call it separately)
-        g = 9.81
-        h_in = (f * V0 + V0 * V0) * r * r / (2.0 * g)
-        h_rmax = (f * V0 + V0 * V0) * Rmax * Rmax / (2.0 * g)
-        rs = np.maximum(r, Rmax)
-        h_out = h_rmax + (f * Rmax ** 2 * V0 * np.log(rs / Rmax) + 0.5 * Rmax ** 4 * V0 ** 2 * (1.0 / Rmax ** 2 - 1.0 / rs ** 2)) / g
-        h = np.where(r < Rmax, h_in, h_out)
-        inner = r < Rmax
-        vp = np.where(inner, 0.5 * zeta * r * (eps * np.cos(2 * l) / Rmax),
-                      0.5 * zeta * (Rmax ** 2 / r) * (-eps * np.cos(2 * l) * Rmax / r ** 2))
-        up = np.where(inner, 0.5 * zeta * r * (eps * np.sin(2 * l) / Rmax),
-                      0.5 * zeta * (Rmax ** 2 / r) * (eps * np.sin(2 * l) * Rmax / r ** 2))
-        return np.stack([h, up, vbar + vp, 0.8 * up, 0.8 * (vbar + vp), 0.0 * r], axis=1)
-    par = dict(g=9.81, K=5000.0, Cd=2.4e-3, Hfree=2000.0, Hb=1000.0, f=5.0e-5, S1=1.0e-4)
-    return dict(name="config2", grid=dict(geometry="RL", xmin=0.0, xmax=3.0e5, num_cells=100, vars=VARS6, BCL=BCL6, BCR=BCR6),
-                eq="Twoway_ShallowWater_Slab" if twoway else "Oneway_ShallowWater_Slab", ts=3.0, par=par, ic=ic)
+from bench_configs import config2_literal     # noqa: E402,F401  (one definition for bench.py and the tests)
 
 
 def config5_case():
@@ -312,27 +288,7 @@ def config5_case():
     return case
 
 
-def config3_rz(num_cells=171, zDim=128):
-    """configs[2]: RZ 513 x 128 with Chebyshev vertical (b_zDim = zDim) and the semi-implicit adjustment.
-
-    SURVEY.md 8(d) asks for a step with c = (1.25 ts)^2 Pxi_bar (2 / Lz)^2 = O(1..100), i.e. a vertical acoustic CFL far
-    above 1 that the AI2* adjustment has to absorb: ts = 2 s on a 1 km deep column gives c = 3.0 (vertical CFL ~ 4,600 at
-    the 0.15 m end spacing of 128 Chebyshev levels).  Everything that stays explicit must then be stable at ts = 2 s:
-    horizontal acoustic waves (sqrt(Pxi_bar) = 346 m/s: DX = 5.8 km, ts c pi / DX = 0.37 < 0.72 for AB3), vertical
-    advection and diffusion against the Chebyshev operators' spectral radii (|w| <= 0.02 m/s, K = 1e-3 m^2/s).  The run is
-    finite for thousands of steps; an unstable choice (the earlier xmax = 10 km, ts = 0.1 s) blows up after 40."""
-    def ic(p):
-        r, z = p[:, 0], p[:, 1]
-        b = np.exp(-((r - 5.0e5) / 2.0e5) ** 2 - ((z - 500.0) / 200.0) ** 2)
-        s = np.sin(np.pi * z / 1.0e3)
-        return np.stack([b, 1.0e-3 * b, 0.5 * b, 0.05 * s * b, 0.02 * s * b], axis=1)
-    c = rz_semiimplicit(num_cells=num_cells, zDim=zDim)
-    c["name"] = "config3"
-    c["grid"].update(xmax=1.0e6, zmax=1.0e3)
-    c["ts"] = 2.0
-    c["par"] = dict(K=1.0e-3, Pxi_bar=1.2e5)
-    c["ic"] = ic
-    return c
+from bench_configs import config3_rz          # noqa: E402,F401
 
 
 # ----------------------------------------------------------------------------- measured accuracy of derivative slots

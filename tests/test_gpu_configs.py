@@ -156,6 +156,54 @@ def test_config4_native_equivalent_full_size_against_the_c_oracle():
     _check(hip, orc, [0, 1, 127, 128, 253, 254], "config 4, native-equivalent shape (255 ragged rings x 64 levels, kmax 255), 2 steps")
 
 
+def _bench_case(num_cells=None, native=False):
+    """bench.py's own workload (grid, boundary conditions, parameters, time step, initial condition) as a test case."""
+    import bench
+    kw, L = bench.grid_kwargs("rlz_513x256x64")
+    if num_cells:
+        kw["num_cells"] = num_cells
+    if not native:
+        kw["ring_L"] = L
+    return dict(name="bench", grid=kw, eq="Oneway_ShallowWater_HeightResolvedBL", ts=bench.TS, par=dict(bench.PAR), ic=bench.initial_condition)
+
+
+def _long_run_against_the_c_oracle(case, nsteps, rings, title, npoints):
+    """HIP path and C oracle side by side for `nsteps` steps: the spectral state (A coefficients) is compared after EVERY step - the
+    measured growth of the difference per step is printed - and state + value slot are held to 1e-10 at the end; the derivative
+    slots by check_full's extended-precision criterion on the sampled rings."""
+    hip = cases.HipModel(case)
+    assert hip.run.tiles[0].N == npoints
+    orc = cases.OracleModel(case)
+    hist = []
+    for t in range(1, nsteps + 1):
+        hip.step()
+        orc.step()
+        hist.append(cases.rel_err(hip.A, orc.A))
+        assert np.isfinite(hist[-1]) and hist[-1] < TOL, (t, hist)
+    growth = (hist[-1] / max(hist[0], 1e-300)) ** (1.0 / max(nsteps - 1, 1))
+    print("\n%s: max relative difference of the A coefficients after step t" % title)
+    print("  " + "  ".join("t=%d %.1e" % (t + 1, e) for t, e in enumerate(hist) if t in (0, 1, 4, 9, 14, 19, 24, nsteps - 1)))
+    print("  geometric growth per step over %d steps: %.3f" % (nsteps, growth))
+    _check(hip, orc, rings, "%s, %d steps" % (title, nsteps))
+    return hist
+
+
+def test_config4_full_size_25_steps_against_the_c_oracle():
+    """Parity at the bench's own length: bench.py times steps 6-25 (driver: --warmup 5 --steps 20) of exactly this configuration -
+    RLZ 513 x 256 x 64, uniform ring table, bench.py's parameters, boundary conditions, time step and initial condition.  25 steps of
+    the HIP path against 25 steps of the C oracle (about a second per step on the box's host cores): A coefficients after every
+    step and the value slot of every variable at the end within 1e-10 (north_star: "fields within 1e-10 rel-err of CPU reference")."""
+    _long_run_against_the_c_oracle(_bench_case(), 25, [0, 1, 125, 126, 127, 300, 512],
+                                   "bench workload (RLZ 513 x 256 x 64, uniform rings) vs the C oracle", 513 * 256 * 64)
+
+
+def test_config4_native_equivalent_10_steps_against_the_c_oracle():
+    """The same over 10 steps on the native-equivalent shape (bench.py's `native_equivalent`: 85 cells = 255 ragged rings x 64 levels,
+    bench.py's parameters and initial condition): the matrix-core DFT kernels over the length of a short timing run."""
+    _long_run_against_the_c_oracle(_bench_case(num_cells=85, native=True), 10, [0, 1, 127, 128, 253, 254],
+                                   "native-equivalent shape (255 ragged rings x 64 levels) vs the C oracle", 8421120)
+
+
 def test_native_rings_of_a_171_cell_patch_beyond_kmax_319():
     """The "512-ring" problem on Springsteel's NATIVE layout: 171 cells = 513 ragged rings of 8 .. 2,052 points keeping up to
     512 wavenumbers (SURVEY.md 8(c) "Layouts"; any num_cells is legal, src/semiimplicit.jl:155-169).  Rings with kmax > 319
