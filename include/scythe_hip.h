@@ -148,6 +148,14 @@ int sx_calc_tile_sizes(const sx_grid_desc *patch, int32_t n_tiles, double *out);
 int sx_cheb_column_ops(double zmin, double zmax, int32_t zDim, int32_t b_zDim, int32_t bcb, int32_t bct, double *z,
                        double *rec, double *dz, double *dzz, double *integ);
 
+/* splineTransform!'s arithmetic for ONE right-hand side on the host, two ways: through the parallel-cyclic-reduction tables the
+ * device kernel k_solve_pcr applies (csrc/sx_pcr.hip: elimination blocks of the constant matrix Gamma (P + eps_q Q) Gamma^T worked
+ * out once in extended precision, applied level by level in double) and through the banded Cholesky factors the serial kernel
+ * k_solve applies.  b, a_pcr, a_chol: [num_cells + 3] patch rows of one spectral column; levels: reduction levels of the tables.
+ * Pure host helper (no handle, no device): it validates the table construction where there is no GPU; never on the step path. */
+int sx_spline_solve_check(int32_t num_cells, double xmin, double xmax, double l_q, int32_t bcl, int32_t bcr, const double *b,
+                          double *a_pcr, double *a_chol, int32_t *levels);
+
 /* --- state in / out (host pointers, reference layouts) ------------------------------------------------------------- */
 /* read_physical_grid -> physical[:, v, 1]  (src/semiimplicit.jl:134): values[n_points, n_vars] */
 int sx_set_physical_values(sx_handle *h, const double *values);

@@ -53,6 +53,7 @@ SYMBOLS = {
     "sx_synchronize": (C.c_int, [_H]),
     "sx_get_gridpoints": (C.c_int, [_H, P_D]),
     "sx_calc_tile_sizes": (C.c_int, [C.POINTER(GridDesc), C.c_int32, P_D]),
+    "sx_spline_solve_check": (C.c_int, [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, P_D, P_D, P_D, C.POINTER(C.c_int32)]),
     "sx_set_physical_values": (C.c_int, [_H, P_D]),
     "sx_get_physical": (C.c_int, [_H, P_D]),
     "sx_get_var_np1": (C.c_int, [_H, P_D]),

@@ -269,6 +269,10 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->fuse_zinv = getenv("SX_FUSE_ZINV") && atoi(getenv("SX_FUSE_ZINV")) != 0;
     h->sbw_prefetch = getenv("SX_SBW_PF") && atoi(getenv("SX_SBW_PF")) != 0;
     h->sbw_mfma = !(getenv("SX_SBW_MFMA") && atoi(getenv("SX_SBW_MFMA")) == 0);
+    h->rz_fused = !(getenv("SX_RZ_FUSED") && atoi(getenv("SX_RZ_FUSED")) == 0);
+    h->semi_mfma = !(getenv("SX_SEMI_MFMA") && atoi(getenv("SX_SEMI_MFMA")) == 0);
+    h->solve_pcr = getenv("SX_SOLVE_PCR") ? atoi(getenv("SX_SOLVE_PCR")) : -1;
+    if (getenv("SX_PCR_MAXCOLS")) h->pcr_maxcols = atoll(getenv("SX_PCR_MAXCOLS"));
     h->cell0 = g->tile_cell0; h->ncells = g->tile_num_cells; h->tile_num = g->tile_num;
     h->nrings = MUBAR * h->ncells; h->nbt = h->ncells + 3;
     for (int i = 0; i < 7; i++) h->slot[i] = DERIV_SLOTS[h->geom][i];
@@ -450,6 +454,12 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
         const ChebOps &cop = ops[h->col_var - 1 < h->V ? h->col_var - 1 : 0];
         std::vector<double> zv = cop.z;
         if (!upload(h, &h->d_Mz, Mz) || !upload(h, &h->d_CB, ops[0].CB) || !upload(h, &h->d_z, zv)) FAIL();
+        {
+            std::vector<double> cbt((size_t)nz * Zb);          // [nz][Zb] for the fused RZ forward kernel (sx_rz.hip)
+            for (int k = 0; k < Zb; k++)
+                for (int i = 0; i < nz; i++) cbt[(size_t)i * Zb + k] = ops[0].CB[(size_t)k * nz + i];
+            if (!upload(h, &h->d_CBT, cbt)) FAIL();
+        }
         if (h->semi) {
             const ChebOps &ox = ops[h->xi_index - 1], &ow = ops[h->w_index - 1];
             if (!upload(h, &h->d_MrecT, transpose(ox.Mrec, nz)) || !upload(h, &h->d_MdzT, transpose(ox.Mdz, nz))) FAIL();
@@ -639,6 +649,7 @@ int sx_destroy(sx_handle *h) {
 #endif
     comm_release(h);
     iface_release(h);
+    pcr_release(h);
     for (auto &p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->event_pool) hipEventDestroy(e);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
@@ -663,6 +674,24 @@ int sx_cheb_column_ops(double zmin, double zmax, int32_t zDim, int32_t b_zDim, i
     if (dz) std::copy(o.Mdz.begin(), o.Mdz.begin() + n2, dz);
     if (dzz) std::copy(o.Mdzz.begin(), o.Mdzz.begin() + n2, dzz);
     if (integ) std::copy(o.Mint.begin(), o.Mint.begin() + n2, integ);
+    return 0;
+}
+
+int sx_spline_solve_check(int32_t num_cells, double xmin, double xmax, double l_q, int32_t bcl, int32_t bcr, const double *b,
+                          double *a_pcr, double *a_chol, int32_t *levels) {
+    clear_error();
+    if (!b || num_cells < 3 || !(xmax > xmin)) { set_error("sx_spline_solve_check: invalid argument"); return 1; }
+    SplineClass sc;
+    PcrTables t;
+    std::string err;
+    const int nb = num_cells + 3;
+    if (!build_spline_class(num_cells, (xmax - xmin) / num_cells, l_q > 0 ? l_q : 2.0, bcl, bcr, sc, err) || !build_pcr_tables(sc, nb, t, err)) {
+        set_error(err);
+        return 1;
+    }
+    if (a_pcr) pcr_apply_host(t, nb, b, a_pcr);
+    if (a_chol) cholesky_apply_host(sc, nb, b, a_chol);
+    if (levels) *levels = t.levels;
     return 0;
 }
 
@@ -1214,6 +1243,8 @@ int sx_kernel_bytes(sx_handle *h, const char *name, double *bytes) {
     else if (k == "k_sbz") b = wi * fl + w * S_tile;
     else if (k == "k_solve") b = w * 4.0 * S_patch;                 // read B, write y, read y, write A
     else if (k == "k_semiimplicit") b = w * N * 2.0 * 5.0;
+    else if (k == "k_rz_inverse") b = w * S_tile + N * out_planes;       // read the tile's A rows, write the requested physical planes
+    else if (k == "k_rz_forward") b = w * N * V + w * S_tile;            // read var_np1, write the tile's B rows
     *bytes = b;
     return 0;
 }

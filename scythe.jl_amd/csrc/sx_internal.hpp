@@ -39,6 +39,27 @@ struct ChebOps {
     std::vector<double> Mdzz;    // [nz][nz]  values -> (CB, CA, CIxx) truncated second derivative
 };
 
+// Parallel-cyclic-reduction form of a spline class's solve a = Gamma^T (Gamma (P + eps_q Q) Gamma^T)^-1 Gamma b (sx_pcr.hip): the free
+// unknowns in blocks of 3 (the half-bandwidth), block-tridiagonal; level l combines block row i with rows i -+ 2^l,
+//   r_i <- r_i - alpha[l][i] r_{i - 2^l} - gamma[l][i] r_{i + 2^l},
+// with the elimination blocks alpha = L D^-1, gamma = U D^-1 of the CONSTANT matrix worked out once, here, in extended precision;
+// after `levels` steps the system is block diagonal (x_i = dinv[i] r_i).  PERIODIC classes: the band part M_b by the same
+// elimination, the corner blocks by a rank-6 correction x = y - G (E^T y) over the first and last three unknowns.
+struct PcrTables {
+    int n = 0, nblk = 0, levels = 0, periodic = 0;
+    std::vector<double> coef;     // [levels][nblk][18]  alpha (3 x 3 row-major), gamma (3 x 3)
+    std::vector<double> dinv;     // [nblk][9]
+    std::vector<int> gin_row;     // [3 nblk][4]  patch rows m whose b enters free unknown j (Gamma b), -1 = none
+    std::vector<double> gin_w;    // [3 nblk][4]
+    std::vector<int> gout_j;      // [nb][2]      free unknowns that make patch row m (Gamma^T x), -1 = none
+    std::vector<double> gout_w;   // [nb][2]
+    std::vector<double> G;        // periodic: [3 nblk][6]
+};
+bool build_pcr_tables(const SplineClass &sc, int nb, PcrTables &out, std::string &err);
+// the same arithmetic the kernel applies (double, level by level), on the host: b / a are patch rows [nb]
+void pcr_apply_host(const PcrTables &t, int nb, const double *b, double *a);
+// the serial statement of the same solve (banded Cholesky factors of build_spline_class), on the host
+void cholesky_apply_host(const SplineClass &sc, int nb, const double *b, double *a);
 void basis_tables(double DX, double phi[4][MUBAR][4]);
 void quad_weights(double DX, double w[MUBAR]);
 int bc_rank(int bc);
@@ -66,6 +87,16 @@ __host__ __device__ inline Planes<ST> planes_of(double *base, int V, int64_t n) 
 
 struct ColJob {
     int64_t in_off, out_off, mat_off;
+};
+
+// semiimplicit_adjustment (src/semiimplicit.jl:521-597): what its kernels need
+struct SemiArgs {
+    double *np1;
+    const double *In, *I1, *I2;
+    const double *MrecT, *MdzT, *WT, *XT;
+    int64_t N;
+    int nz, t, wi, xi;
+    double ts, tau, pxi;
 };
 
 struct Timer {
@@ -155,6 +186,12 @@ struct sx_handle {
     unsigned long long *d_maxabs = nullptr;   // [V] scratch of sx_max_abs
     void *comm_state = nullptr;               // RCCL exchange state (sx_comm.cpp)
     void *iface_state = nullptr;              // interface-only patch solve (sx_iface.hip)
+    void *pcr_state = nullptr;                // parallel-cyclic-reduction tables and launch lists (sx_pcr.hip)
+    int solve_pcr = -1;                       // SX_SOLVE_PCR read at sx_create: 0 never, 1 wherever the tables exist, -1 by column count
+    int64_t pcr_maxcols = 16384;              // SX_PCR_MAXCOLS
+    int rz_fused = 1;                         // RZ grids: the fused radius-on-the-matrix-cores kernels of sx_rz.hip (SX_RZ_FUSED=0: the general kernels)
+    double *d_CBT = nullptr;                  // CB transposed [nz][Zb] (sx_rz.hip)
+    int semi_mfma = 1;                        // semi-implicit column operators on the matrix cores (SX_SEMI_MFMA=0: k_semiimplicit)
     std::vector<sx::SplineClass> classes;     // host copies of the spline classes (d_cls indexes them)
     std::vector<int> hcls;                    // host copy of d_cls: [v][2] -> class of (k = 0, k >= 1)
     int *d_mask_full = nullptr, *d_mask_eq = nullptr;   // per-variable bit masks of derivative slots to produce
@@ -215,6 +252,14 @@ int error_status();   // 1 if set_error has been called since the last clear_err
 void comm_release(sx_handle *h);
 void flush_diag(sx_handle *h);
 void iface_release(sx_handle *h);
+void pcr_release(sx_handle *h);
+bool rz_fused(const sx_handle *h);
+void launch_rz_inverse(sx_handle *h, const int *d_mask);
+void launch_rz_forward(sx_handle *h);
+void launch_semi_mfma(sx_handle *h, const SemiArgs &a);
+bool pcr_wanted(sx_handle *h, int64_t ncols);
+void launch_solve_pcr(sx_handle *h, bool linear, const double *Bsrc, const int64_t *boffA, const int64_t *boffB, double *A,
+                      const int64_t *aoffA, const int64_t *aoffB, int vz0, int ng, int64_t stride);
 bool tile_table_ok(const sx_handle *h, int n, int me, const int32_t *cell0, const int32_t *ncells);
 #ifdef SX_PHASES
 void phases_dump();

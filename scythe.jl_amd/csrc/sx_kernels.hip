@@ -1651,15 +1651,6 @@ __global__ void __launch_bounds__(LAM * NZ, 2) k_phys_hrbl_cell(PhysArgsT<ST> a,
 }
 
 // semiimplicit_adjustment (src/semiimplicit.jl:521-597), one workgroup per group of columns
-struct SemiArgs {
-    double *np1;
-    const double *In, *I1, *I2;
-    const double *MrecT, *MdzT, *WT, *XT;
-    int64_t N;
-    int nz, t, wi, xi;
-    double ts, tau, pxi;
-};
-
 __global__ void __launch_bounds__(256) k_semiimplicit(SemiArgs a, int cpb) {
     extern __shared__ double sm[];
     const int nz = a.nz;
@@ -1746,7 +1737,7 @@ static long long *phases_buffer(int64_t nwg) {
 #endif
 
 void launch_zinv(sx_handle *h, bool full) {
-    if (!h->has_z) return;
+    if (!h->has_z || rz_fused(h)) return;          // RZ: the vertical inverse is part of k_rz_inverse (sx_rz.hip)
     const int id = timer_id(h, "k_zinv");
     timer_begin(h, id);
     const int njobs = full ? h->njobs_zinv_full : h->njobs_zinv_eq;
@@ -1783,6 +1774,7 @@ void launch_rl_inverse(sx_handle *h, bool full) {
     const int *mask = full ? h->d_mask_full : h->d_mask_eq;
     h->last_mask_full = full;
     h->node_active = (!full && h->node_mode);
+    if (rz_fused(h)) { launch_rz_inverse(h, mask); return; }
     if (h->node_active) {            // sx_advance on uniform rings: node-space transforms + ring-wise inner rings only
         launch_node_fft(h);
         launch_rl_inverse_fft(h, mask, h->R_in);
@@ -1921,9 +1913,12 @@ static void launch_physics_t(sx_handle *h, int t, int part) {
         s.MrecT = h->d_MrecT; s.MdzT = h->d_MdzT; s.WT = h->d_WT[which]; s.XT = h->d_XT[which];
         s.N = h->N; s.nz = h->nz; s.t = t; s.wi = h->w_index - 1; s.xi = h->xi_index - 1;
         s.ts = h->ts; s.tau = h->tau[which]; s.pxi = h->par[SX_P_PXI_BAR];
-        const int cpb = h->nz >= 256 ? 1 : 256 / h->nz;
-        const size_t lds = sizeof(double) * 3 * cpb * h->nz;
-        hipLaunchKernelGGL(k_semiimplicit, grid1(h->Nh, cpb), dim3(cpb * h->nz), lds, h->stream, s, cpb);
+        if (h->semi_mfma) launch_semi_mfma(h, s);       // the four column operators on the matrix cores (sx_rz.hip)
+        else {
+            const int cpb = h->nz >= 256 ? 1 : 256 / h->nz;
+            const size_t lds = sizeof(double) * 3 * cpb * h->nz;
+            hipLaunchKernelGGL(k_semiimplicit, grid1(h->Nh, cpb), dim3(cpb * h->nz), lds, h->stream, s, cpb);
+        }
         HIPCHK(hipGetLastError());
         timer_end(h);
     }
@@ -1973,6 +1968,7 @@ void launch_inverse_and_physics(sx_handle *h, int t) {
 }
 
 void launch_fl_forward(sx_handle *h) {
+    if (rz_fused(h)) return;                        // RZ: k_rz_forward reads var_np1 itself (no azimuth, nothing to transform)
     if (fft_path_ok(h)) { launch_fl_forward_fft(h); return; }
     if (dft_mfma_ok(h)) { launch_fl_forward_dft(h); return; }
     const int id = timer_id(h, "k_fl_forward");
@@ -1991,6 +1987,7 @@ void launch_fl_forward(sx_handle *h) {
 }
 
 void launch_sb(sx_handle *h) {
+    if (rz_fused(h)) { launch_rz_forward(h); return; }
     if (h->has_z) {        // fused with the vertical forward transform
         const int id = timer_id(h, "k_sbz");
         timer_begin(h, id);
@@ -2058,7 +2055,18 @@ void launch_solve(sx_handle *h) {
     const int id = timer_id(h, "k_solve");
     timer_begin(h, id);
     dim3 g((h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1, h->V * h->Zb);
-    if (h->d_Bsrc == h->d_Bfull) {   // internal contiguous B: no offset tables needed; the variable window through the base pointers
+    // few right-hand sides (the R grid's one column, RZ grids, small RL patches): LDS-staged parallel cyclic reduction (sx_pcr.hip)
+    // instead of one wave's serial recurrence per 64 columns
+    const bool contiguous = (h->d_Bsrc == h->d_Bfull);
+    const int ngroups = contiguous ? h->v_cnt * h->Zb : h->V * h->Zb;
+    if (pcr_wanted(h, (int64_t)ngroups * (h->K2 > 1 ? h->K2 - 1 : 1))) {
+        const int64_t clo = contiguous ? (int64_t)h->v_lo * h->Zb * h->K2 : 0;
+        launch_solve_pcr(h, contiguous, h->d_Bsrc + clo, h->d_rowoff, h->d_neg1, h->d_A + clo, h->d_aoff, h->d_neg1,
+                         contiguous ? h->v_lo * h->Zb : 0, ngroups, h->C);
+        timer_end(h);
+        return;
+    }
+    if (contiguous) {   // internal contiguous B: no offset tables needed; the variable window through the base pointers
         const int64_t clo = (int64_t)h->v_lo * h->Zb * h->K2;
         g.y = h->v_cnt * h->Zb;
         hipLaunchKernelGGL(k_solve<true>, g, dim3(64), sizeof(double) * 4 * h->b_rDim, h->stream, h->d_Bsrc + clo, h->d_rowoff, h->d_neg1, h->d_A + clo, h->d_aoff, h->d_neg1,
@@ -2079,6 +2087,11 @@ void launch_solve_a2a(sx_handle *h, const double *recv, double *send) {
     const int id = timer_id(h, "k_solve");
     timer_begin(h, id);
     const int ng = h->a2a_g1 - h->a2a_g0;
+    if (ng > 0 && pcr_wanted(h, (int64_t)ng * (h->K2 > 1 ? h->K2 - 1 : 1))) {
+        launch_solve_pcr(h, false, recv, h->d_a2a_offA, h->d_a2a_offB, send, h->d_a2a_offA, h->d_a2a_offB, h->a2a_g0, ng, 0);
+        timer_end(h);
+        return;
+    }
     if (ng > 0) {
         const int bx_pair = (h->K2 > 1 ? (h->K2 / 2 - 1 + 63) / 64 : 0) + 1;
         const bool single = (int64_t)bx_pair * ng < 768 && h->K2 > 2;        // fewer waves than SIMDs: one column per lane

@@ -5,6 +5,7 @@
 // Cholesky factorisation, Chebyshev collocation / derivative / integral operators - following SURVEY.md 8(c).
 // The quadrature-weight ratio 8:5:8 is the one the reference's notebook known-answer pins.
 #include "sx_internal.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -153,6 +154,241 @@ bool build_spline_class(int nc, double DX, double l_q, int bcl, int bcr, SplineC
         for (int r = 0; r < 3; r++)
             for (int k = 0; k <= n - 3 + r; k++) out.Larrow[(size_t)r * nb + k] = A[(size_t)(n - 3 + r) * n + k];
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------- parallel cyclic reduction tables
+typedef long double pxr;
+struct B3 { pxr a[9]; };
+static B3 b3_zero() { B3 z; for (int i = 0; i < 9; i++) z.a[i] = 0.0L; return z; }
+static B3 b3_mul(const B3 &x, const B3 &y) {
+    B3 r = b3_zero();
+    for (int i = 0; i < 3; i++)
+        for (int k = 0; k < 3; k++)
+            for (int j = 0; j < 3; j++) r.a[i * 3 + j] += x.a[i * 3 + k] * y.a[k * 3 + j];
+    return r;
+}
+static B3 b3_sub(const B3 &x, const B3 &y) { B3 r; for (int i = 0; i < 9; i++) r.a[i] = x.a[i] - y.a[i]; return r; }
+static bool b3_inv(const B3 &m, B3 &out) {
+    const pxr *a = m.a;
+    const pxr c00 = a[4] * a[8] - a[5] * a[7], c01 = a[5] * a[6] - a[3] * a[8], c02 = a[3] * a[7] - a[4] * a[6];
+    const pxr det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+    if (det == 0.0L) return false;
+    const pxr id = 1.0L / det;
+    out.a[0] = c00 * id; out.a[1] = (a[2] * a[7] - a[1] * a[8]) * id; out.a[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+    out.a[3] = c01 * id; out.a[4] = (a[0] * a[8] - a[2] * a[6]) * id; out.a[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+    out.a[6] = c02 * id; out.a[7] = (a[1] * a[6] - a[0] * a[7]) * id; out.a[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+    return true;
+}
+static pxr b3_norm(const B3 &m) { pxr s = 0.0L; for (int i = 0; i < 9; i++) s = std::max(s, fabsl(m.a[i])); return s; }
+
+bool build_pcr_tables(const SplineClass &sc, int nb, PcrTables &t, std::string &err) {
+    const int n = sc.nfree;
+    t.n = n; t.periodic = sc.periodic;
+    t.nblk = (n + 2) / 3;
+    const int np = 3 * t.nblk;
+    if ((int)sc.Mdense.size() != n * n) { err = "build_pcr_tables: the class has no dense matrix"; return false; }
+    auto Mc = [&](int i, int j) -> pxr { return (pxr)sc.Mdense[(size_t)i * n + j]; };
+    // band part (PERIODIC: the corner blocks leave through the rank-6 correction below); padding unknowns are identity rows
+    auto Mb = [&](int i, int j) -> pxr {
+        if (i >= n || j >= n) return i == j ? 1.0L : 0.0L;
+        return std::abs(i - j) <= 3 ? Mc(i, j) : 0.0L;
+    };
+    std::vector<B3> Lb(t.nblk), Db(t.nblk), Ub(t.nblk);
+    for (int i = 0; i < t.nblk; i++) {
+        Lb[i] = Db[i] = Ub[i] = b3_zero();
+        for (int p = 0; p < 3; p++)
+            for (int q = 0; q < 3; q++) {
+                Db[i].a[p * 3 + q] = Mb(3 * i + p, 3 * i + q);
+                if (i > 0) Lb[i].a[p * 3 + q] = Mb(3 * i + p, 3 * (i - 1) + q);
+                if (i + 1 < t.nblk) Ub[i].a[p * 3 + q] = Mb(3 * i + p, 3 * (i + 1) + q);
+            }
+    }
+    t.coef.clear();
+    t.levels = 0;
+    for (int s = 1; s < 2 * t.nblk; s <<= 1) {
+        pxr off = 0.0L, dia = 0.0L;
+        for (int i = 0; i < t.nblk; i++) { off = std::max(off, std::max(b3_norm(Lb[i]), b3_norm(Ub[i]))); dia = std::max(dia, b3_norm(Db[i])); }
+        // block diagonal already - exactly (s >= nblk) or far below anything a double-precision right-hand side can see
+        if (off == 0.0L || off < dia * 1e-34L) break;
+        std::vector<B3> Di(t.nblk), Ln(t.nblk), Dn(t.nblk), Un(t.nblk);
+        for (int i = 0; i < t.nblk; i++)
+            if (!b3_inv(Db[i], Di[i])) { err = "build_pcr_tables: singular diagonal block"; return false; }
+        const size_t base = t.coef.size();
+        t.coef.resize(base + (size_t)t.nblk * 18, 0.0);
+        for (int i = 0; i < t.nblk; i++) {
+            B3 al = b3_zero(), ga = b3_zero();
+            Dn[i] = Db[i]; Ln[i] = b3_zero(); Un[i] = b3_zero();
+            if (i - s >= 0) {
+                al = b3_mul(Lb[i], Di[i - s]);
+                Dn[i] = b3_sub(Dn[i], b3_mul(al, Ub[i - s]));
+                Ln[i] = b3_sub(b3_zero(), b3_mul(al, Lb[i - s]));
+            }
+            if (i + s < t.nblk) {
+                ga = b3_mul(Ub[i], Di[i + s]);
+                Dn[i] = b3_sub(Dn[i], b3_mul(ga, Lb[i + s]));
+                Un[i] = b3_sub(b3_zero(), b3_mul(ga, Ub[i + s]));
+            }
+            for (int q = 0; q < 9; q++) {
+                t.coef[base + (size_t)i * 18 + q] = (double)al.a[q];
+                t.coef[base + (size_t)i * 18 + 9 + q] = (double)ga.a[q];
+            }
+        }
+        Lb.swap(Ln); Db.swap(Dn); Ub.swap(Un);
+        t.levels++;
+    }
+    t.dinv.assign((size_t)t.nblk * 9, 0.0);
+    for (int i = 0; i < t.nblk; i++) {
+        B3 di;
+        if (!b3_inv(Db[i], di)) { err = "build_pcr_tables: singular reduced block"; return false; }
+        for (int q = 0; q < 9; q++) t.dinv[(size_t)i * 9 + q] = (double)di.a[q];
+    }
+    // Gamma b and Gamma^T x as gather tables
+    t.gin_row.assign((size_t)np * 4, -1); t.gin_w.assign((size_t)np * 4, 0.0);
+    t.gout_j.assign((size_t)nb * 2, -1); t.gout_w.assign((size_t)nb * 2, 0.0);
+    std::vector<int> cnt_out(nb, 0);
+    for (int j = 0; j < n; j++) {
+        if (sc.Gam[j].size() > 4) { err = "build_pcr_tables: more than 4 patch rows per free unknown"; return false; }
+        int q = 0;
+        for (auto &e : sc.Gam[j]) {
+            t.gin_row[(size_t)j * 4 + q] = e.first; t.gin_w[(size_t)j * 4 + q] = e.second; q++;
+            if (cnt_out[e.first] >= 2) { err = "build_pcr_tables: more than 2 free unknowns per patch row"; return false; }
+            t.gout_j[(size_t)e.first * 2 + cnt_out[e.first]] = j; t.gout_w[(size_t)e.first * 2 + cnt_out[e.first]] = e.second;
+            cnt_out[e.first]++;
+        }
+    }
+    t.G.clear();
+    if (sc.periodic) {
+        // M_c = M_b + E C E^T over the edge unknowns e = {0, 1, 2, n-3, n-2, n-1};  x = y - W (I + C E^T W)^-1 C E^T y,  W = M_b^-1 E
+        if (n < 7) { err = "build_pcr_tables: periodic class with fewer than 7 unknowns"; return false; }
+        const int e[6] = {0, 1, 2, n - 3, n - 2, n - 1};
+        // W by banded Gaussian elimination (no pivoting: M_b is symmetric positive definite) in extended precision
+        std::vector<pxr> band((size_t)n * 7), W((size_t)n * 6, 0.0L);
+        for (int i = 0; i < n; i++)
+            for (int d = -3; d <= 3; d++) band[(size_t)i * 7 + d + 3] = (i + d >= 0 && i + d < n) ? Mb(i, i + d) : 0.0L;
+        for (int q = 0; q < 6; q++) W[(size_t)e[q] * 6 + q] = 1.0L;
+        for (int k = 0; k < n; k++) {
+            const pxr piv = band[(size_t)k * 7 + 3];
+            if (!(piv > 0.0L)) { err = "build_pcr_tables: band part of the periodic matrix is not positive definite"; return false; }
+            for (int i = k + 1; i <= std::min(n - 1, k + 3); i++) {
+                const pxr f = band[(size_t)i * 7 + (k - i) + 3] / piv;
+                if (f == 0.0L) continue;
+                for (int j = k; j <= std::min(n - 1, k + 3); j++) band[(size_t)i * 7 + (j - i) + 3] -= f * band[(size_t)k * 7 + (j - k) + 3];
+                for (int q = 0; q < 6; q++) W[(size_t)i * 6 + q] -= f * W[(size_t)k * 6 + q];
+            }
+        }
+        for (int k = n - 1; k >= 0; k--)
+            for (int q = 0; q < 6; q++) {
+                pxr s = W[(size_t)k * 6 + q];
+                for (int j = k + 1; j <= std::min(n - 1, k + 3); j++) s -= band[(size_t)k * 7 + (j - k) + 3] * W[(size_t)j * 6 + q];
+                W[(size_t)k * 6 + q] = s / band[(size_t)k * 7 + 3];
+            }
+        pxr C[6][6], S[6][6], Si[6][6];
+        for (int p = 0; p < 6; p++)
+            for (int q = 0; q < 6; q++) C[p][q] = std::abs(e[p] - e[q]) > 3 ? Mc(e[p], e[q]) : 0.0L;
+        for (int p = 0; p < 6; p++)
+            for (int q = 0; q < 6; q++) {
+                pxr s = p == q ? 1.0L : 0.0L;
+                for (int k = 0; k < 6; k++) s += C[p][k] * W[(size_t)e[k] * 6 + q];
+                S[p][q] = s;
+                Si[p][q] = p == q ? 1.0L : 0.0L;
+            }
+        for (int c = 0; c < 6; c++) {            // Gauss-Jordan with partial pivoting, 6 x 6
+            int piv = c;
+            for (int r = c + 1; r < 6; r++) if (fabsl(S[r][c]) > fabsl(S[piv][c])) piv = r;
+            if (S[piv][c] == 0.0L) { err = "build_pcr_tables: singular periodic correction"; return false; }
+            for (int j = 0; j < 6; j++) { std::swap(S[piv][j], S[c][j]); std::swap(Si[piv][j], Si[c][j]); }
+            const pxr d = 1.0L / S[c][c];
+            for (int j = 0; j < 6; j++) { S[c][j] *= d; Si[c][j] *= d; }
+            for (int r = 0; r < 6; r++) {
+                if (r == c) continue;
+                const pxr f = S[r][c];
+                for (int j = 0; j < 6; j++) { S[r][j] -= f * S[c][j]; Si[r][j] -= f * Si[c][j]; }
+            }
+        }
+        pxr SC[6][6];
+        for (int p = 0; p < 6; p++)
+            for (int q = 0; q < 6; q++) { pxr s = 0.0L; for (int k = 0; k < 6; k++) s += Si[p][k] * C[k][q]; SC[p][q] = s; }
+        t.G.assign((size_t)np * 6, 0.0);
+        for (int i = 0; i < n; i++)
+            for (int q = 0; q < 6; q++) { pxr s = 0.0L; for (int k = 0; k < 6; k++) s += W[(size_t)i * 6 + k] * SC[k][q]; t.G[(size_t)i * 6 + q] = (double)s; }
+    }
+    return true;
+}
+
+void pcr_apply_host(const PcrTables &t, int nb, const double *b, double *a) {
+    const int np = 3 * t.nblk;
+    std::vector<double> r(np, 0.0), rn(np, 0.0);
+    for (int j = 0; j < t.n; j++) {
+        double s = 0.0;
+        for (int q = 0; q < 4; q++) if (t.gin_row[(size_t)j * 4 + q] >= 0) s += t.gin_w[(size_t)j * 4 + q] * b[t.gin_row[(size_t)j * 4 + q]];
+        r[j] = s;
+    }
+    for (int l = 0; l < t.levels; l++) {
+        const int s = 1 << l;
+        for (int i = 0; i < t.nblk; i++) {
+            const double *c = t.coef.data() + ((size_t)l * t.nblk + i) * 18;
+            for (int p = 0; p < 3; p++) {
+                double v = r[3 * i + p];
+                for (int q = 0; q < 3; q++) {
+                    if (i - s >= 0) v -= c[p * 3 + q] * r[3 * (i - s) + q];
+                    if (i + s < t.nblk) v -= c[9 + p * 3 + q] * r[3 * (i + s) + q];
+                }
+                rn[3 * i + p] = v;
+            }
+        }
+        r.swap(rn);
+    }
+    std::vector<double> x(np, 0.0);
+    for (int i = 0; i < t.nblk; i++)
+        for (int p = 0; p < 3; p++) {
+            double v = 0.0;
+            for (int q = 0; q < 3; q++) v += t.dinv[(size_t)i * 9 + p * 3 + q] * r[3 * i + q];
+            x[3 * i + p] = v;
+        }
+    if (t.periodic) {
+        const int e[6] = {0, 1, 2, t.n - 3, t.n - 2, t.n - 1};
+        double ye[6];
+        for (int q = 0; q < 6; q++) ye[q] = x[e[q]];
+        for (int i = 0; i < t.n; i++) {
+            double v = x[i];
+            for (int q = 0; q < 6; q++) v -= t.G[(size_t)i * 6 + q] * ye[q];
+            x[i] = v;
+        }
+    }
+    for (int m = 0; m < nb; m++) {
+        double s = 0.0;
+        for (int q = 0; q < 2; q++) if (t.gout_j[(size_t)m * 2 + q] >= 0) s += t.gout_w[(size_t)m * 2 + q] * x[t.gout_j[(size_t)m * 2 + q]];
+        a[m] = s;
+    }
+}
+
+void cholesky_apply_host(const SplineClass &sc, int nb, const double *b, double *a) {
+    // dense statement of what k_solve computes: rhs = Gamma b, L L^T x = rhs with the class's factor rows, a = Gamma^T x
+    const int n = sc.nfree;
+    std::vector<long double> rhs(n, 0.0L), y(n), x(n);
+    for (int j = 0; j < n; j++)
+        for (auto &e : sc.Gam[j]) rhs[j] += (long double)e.second * b[e.first];
+    auto Lf = [&](int i, int j) -> long double {          // factor entry (i >= j)
+        if (i - j <= 3) return sc.Lband[(size_t)i * 4 + (3 - (i - j))];
+        if (sc.periodic && i >= n - 3) return sc.Larrow[(size_t)(i - (n - 3)) * nb + j];
+        return 0.0L;
+    };
+    for (int i = 0; i < n; i++) {
+        long double s = rhs[i];
+        for (int j = (sc.periodic && i >= n - 3) ? 0 : std::max(0, i - 3); j < i; j++) s -= Lf(i, j) * y[j];
+        y[i] = s / Lf(i, i);
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        long double s = y[i];
+        for (int j = i + 1; j < n; j++) {
+            const long double l = Lf(j, i);
+            if (l != 0.0L) s -= l * x[j];
+        }
+        x[i] = s / Lf(i, i);
+    }
+    for (int m = 0; m < nb; m++) a[m] = 0.0;
+    for (int j = 0; j < n; j++)
+        for (auto &e : sc.Gam[j]) a[e.first] += (double)((long double)e.second * x[j]);
 }
 
 // ---------------------------------------------------------------------------------------------- Chebyshev

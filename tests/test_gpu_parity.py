@@ -254,6 +254,95 @@ def test_patch_spectral_assembled_from_tiles_is_the_one_patch_array(maker, kw, n
     assert cases.rel_err_per_var(g1.physical, phys) < TOL
 
 
+@pytest.mark.parametrize("maker,kw", [(cases.r_bcs, {"bcl": "R0", "bcr": "R0", "num_cells": 40}), (cases.r_bcs, {"bcl": "R1T0", "bcr": "R1T1", "num_cells": 171}),
+                                      (cases.r_bcs, {"bcl": "R1T2", "bcr": "R2T10", "num_cells": 33}), (cases.r_bcs, {"bcl": "R2T20", "bcr": "R3", "num_cells": 64}),
+                                      (cases.r_bcs, {"bcl": "R3", "bcr": "R1T0", "num_cells": 7}), (cases.r_bcs, {"bcl": "R1T1", "bcr": "R0", "num_cells": 400}),
+                                      (cases.kat_r, {}), (cases.kat_r, {"num_cells": 7}), (cases.kat_r, {"num_cells": 101}),
+                                      (cases.rz_semiimplicit, {"num_cells": 21, "zDim": 16}), (cases.rl_slab, {"num_cells": 20}),
+                                      (cases.rl_slab, {"num_cells": 12, "ring_L": 64}), (cases.rlz_hrbl, {"num_cells": 9, "zDim": 10})])
+def test_parallel_cyclic_reduction_solve_equals_the_serial_cholesky_solve(monkeypatch, maker, kw):
+    """splineTransform! two ways on the device, on random B coefficients: the LDS-staged parallel cyclic reduction (k_solve_pcr,
+    csrc/sx_pcr.hip: what launches with few right-hand sides take) against the lane-per-column banded Cholesky recurrence (k_solve),
+    for every radial boundary-condition class incl. PERIODIC, the k = 0 / k >= 1 class split of RL / RLZ grids and the single column
+    per group of RZ grids - and both against the oracle's dense definition of the solve."""
+    import scythe_jl_amd as S
+    case = maker(**kw)
+    gp, mp = cases.hip_params(case)
+    monkeypatch.setenv("SX_SOLVE_PCR", "1")
+    g1 = S.Grid(gp, mp)
+    monkeypatch.setenv("SX_SOLVE_PCR", "0")
+    g0 = S.Grid(gp, mp)
+    rng = np.random.default_rng(5)
+    shared = rng.standard_normal((int(g1.dims.s_patch), g1.V))
+    out = []
+    for g in (g1, g0):
+        g.set_patch_spectral_b(shared)
+        g.splineTransform_()
+        out.append(g.patchSpectral)
+    assert np.abs(out[0]).max() > 0
+    assert cases.rel_err(out[0], out[1]) < 1e-13
+    ref = cases.oracle_grid(case).spline_transform(np.asfortranarray(shared))      # the numpy oracle's dense definition (Spline1D.SA)
+    assert cases.rel_err(out[0], ref) < 1e-12
+    g1.close()
+    g0.close()
+
+
+@pytest.mark.parametrize("num_cells,zDim,b_zDim", [(5, 9, None), (21, 33, 20), (40, 64, None), (16, 128, 128), (7, 17, 17), (33, 250, 100)])
+def test_rz_fused_matrix_core_transforms_equal_the_general_kernels(monkeypatch, num_cells, zDim, b_zDim):
+    """RZ grids: tileTransform! and spectralTransform! through the fused radius-on-the-matrix-cores kernels (csrc/sx_rz.hip,
+    the default) against the general vertical + radial kernels (SX_RZ_FUSED=0) on random coefficients / fields: every derivative
+    slot and every B coefficient, level and mode counts that are not multiples of the 16 x 16 x 4 tile included."""
+    import scythe_jl_amd as S
+    case = cases.rz_advection(num_cells=num_cells, zDim=zDim)
+    if b_zDim:
+        case["grid"]["b_zDim"] = b_zDim
+    gp, mp = cases.hip_params(case)
+    g1 = S.Grid(gp, mp)
+    monkeypatch.setenv("SX_RZ_FUSED", "0")
+    g0 = S.Grid(gp, mp)
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal((int(g1.dims.s_patch), g1.V))
+    vals = rng.standard_normal((g1.N, g1.V))
+    res = []
+    for g in (g1, g0):
+        g.set_patch_spectral_a(a)
+        g.tileTransform_()
+        ph = g.physical
+        g.set_physical_values(vals)
+        g.spectralTransform_()
+        res.append((ph, g.spectral))
+    assert np.abs(res[0][0]).max() > 0 and np.abs(res[0][1]).max() > 0
+    for d in range(res[0][0].shape[2]):
+        assert cases.rel_err(res[0][0][:, :, d], res[1][0][:, :, d]) < 1e-12, d
+    assert cases.rel_err(res[0][1], res[1][1]) < 1e-13
+    g1.close()
+    g0.close()
+
+
+@pytest.mark.parametrize("num_cells,zDim", [(8, 12), (10, 33), (6, 64), (9, 128), (5, 200)])
+def test_semi_implicit_adjustment_on_the_matrix_cores_equals_the_scalar_kernel(monkeypatch, num_cells, zDim):
+    """semiimplicit_adjustment (src/semiimplicit.jl:521-597): the four column operators as f64-MFMA products of 16 columns
+    (k_semi_mfma, csrc/sx_rz.hip, the default) against the scalar kernel (SX_SEMI_MFMA=0) - Euler, AB2 and AB3 steps, level counts
+    that are not multiples of the tile - and against the oracle."""
+    case = cases.rz_semiimplicit(num_cells=num_cells, zDim=zDim)
+    a = cases.HipModel(case)
+    monkeypatch.setenv("SX_SEMI_MFMA", "0")
+    b = cases.HipModel(case)
+    orc = cases.OracleModel(case)
+    for _ in range(5):
+        a.step()
+        b.step()
+        orc.step()
+    fa, fb = a.run.tiles[0].var_np1, b.run.tiles[0].var_np1
+    assert np.isfinite(fa).all()
+    for v in range(fa.shape[1]):
+        assert np.abs(fa[:, v] - fb[:, v]).max() <= 1e-12 * max(np.abs(fb[:, v]).max(), 1e-300), v
+    pa, po = a.physical(), orc.physical()
+    assert cases.rel_err_per_var(pa[:, :, :1], po[:, :, :1]) < TOL          # the model fields
+    if zDim <= 33:          # (beyond that the d2/dz2 slot of two fp64 runs differs by N^4 eps: tests/test_gpu_configs.py treats config 3)
+        assert cases.rel_err_per_var(pa, po) < TOL
+
+
 def test_interface_only_solve_refuses_tiles_that_are_too_small():
     import scythe_jl_amd as S
     case = cases.rl_slab(num_cells=9)
