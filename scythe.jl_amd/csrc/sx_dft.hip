@@ -19,6 +19,7 @@
 // vertical level.
 #include "sx_internal.hpp"
 #include <algorithm>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -685,6 +686,206 @@ k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------ RL grids, quarter-wave forms
+// Round 4.  The two RL kernels above transform the HALF ring (l = 0 .. L/2) and were launched in two ring classes x column groups.
+// Every native ring length is a multiple of 4, so - as on RLZ grids - only l = 0 .. L/4 needs transforming, the even and the odd
+// wavenumbers in separate accumulators: half the matrix-core work.  One launch over a work list (ring, part), most expensive
+// first; all column groups of a ring inside one workgroup, so a fetched twiddle feeds 2 MFMAs per group (4 for the 19 planes
+// of the slab sets) and the coefficient tiles of a ring are staged once per part instead of once per part and group.
+constexpr int KCHQ = 96;      // wavenumbers per staged chunk of the RL inverse (a multiple of 8)
+
+template <class ST, int NG>
+__global__ void __launch_bounds__(512)
+k_rl_inverse_dft_planes_q(const double *__restrict__ A, Planes<ST> phys, const double *__restrict__ phi, const int *__restrict__ Lr,
+                          const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
+                          const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
+                          int K2, int nrings, int64_t N, int64_t arow, PlaneGroups pgs, const int *__restrict__ items, int lcap) {
+    extern __shared__ double sm[];
+    const int ring = items[2 * blockIdx.x], part = items[2 * blockIdx.x + 1];
+    const int L = Lr[ring], km = kmaxr[ring], Lh = L / 2, Lq = L / 4;
+    double2 *twl = reinterpret_cast<double2 *>(sm);
+    constexpr int CW = NG * CSTP;                              // row stride of the merged coefficient tile: NG groups of 16 (+1) columns
+    double *Cc = sm + 2 * (size_t)lcap;                         // [KCHQ][CW]
+    double *Cs = Cc + (size_t)KCHQ * CW;
+    const int j0 = ring / MUBAR;
+    const double2 *phr = ph + phoff[ring];
+    const int64_t p0 = pstart[ring];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
+    const double *pf = phi + (int64_t)ring * 4;
+    const int i = lane & 15, kk = lane >> 4;
+    const int mt = part * nw + wave;                            // this wave's row tile of the quarter ring (points mt * 16 .. + 15 of 0 .. L/4)
+    const bool rows = mt * 16 <= Lq;
+    const int lrow = min(mt * 16 + i, Lq);
+    const int sm8 = (int)(((int64_t)8 * lrow) % L);
+    dft_d4 P[NG][2], Q[NG][2];
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+        for (int par = 0; par < 2; par++) { P[g][par] = dft_d4{0.0, 0.0, 0.0, 0.0}; Q[g][par] = P[g][par]; }
+    for (int kc0 = 0; kc0 <= km; kc0 += KCHQ) {
+        const int kend = min(km, kc0 + KCHQ - 1), kn = kend - kc0 + 1;
+        __syncthreads();                                        // the previous chunk has been consumed (and twl is complete)
+        for (int e = tid; e < KCHQ * CW; e += blockDim.x) { Cc[e] = 0.0; Cs[e] = 0.0; }
+        __syncthreads();
+        for (int e = tid; e < V * kn; e += blockDim.x) {
+            const int kl = e % kn, k = kc0 + kl, v = e / kn;
+            const double *a = A + (int64_t)j0 * arow + (int64_t)v * K2 + 2 * k;
+            const double2 r0 = *reinterpret_cast<const double2 *>(a), r1 = *reinterpret_cast<const double2 *>(a + arow),
+                          r2 = *reinterpret_cast<const double2 *>(a + 2 * arow), r3 = *reinterpret_cast<const double2 *>(a + 3 * arow);
+            double cr[3], ci[3];
+            const double2 w = phr[k];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const double *f = pf + (int64_t)d * nrings * 4;
+                cr[d] = f[0] * r0.x + f[1] * r1.x + f[2] * r2.x + f[3] * r3.x;
+                ci[d] = (k == 0) ? 0.0 : f[0] * r0.y + f[1] * r1.y + f[2] * r2.y + f[3] * r3.y;
+                if (k > 0) {
+                    const double tr = cr[d] * w.x - ci[d] * w.y;
+                    ci[d] = 2.0 * (cr[d] * w.y + ci[d] * w.x);
+                    cr[d] = 2.0 * tr;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+#pragma unroll
+                for (int kind = 0; kind < 5; kind++) {
+                    const int c = pgs.g[g].colof[v][kind];
+                    if (c < 0) continue;
+                    double xr, xi;
+                    if (kind < 3) { xr = cr[kind]; xi = ci[kind]; }
+                    else if (kind == 3) { xr = -(double)k * ci[0]; xi = (double)k * cr[0]; }
+                    else { xr = -((double)k * k) * cr[0]; xi = -((double)k * k) * ci[0]; }
+                    Cc[kl * CW + g * CSTP + c] = xr;
+                    Cs[kl * CW + g * CSTP + c] = xi;
+                }
+            }
+        }
+        __syncthreads();
+        if (!rows) continue;
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            // this lane's wavenumber k = kc0 + 8 js + 2 kk + par; angle index (k l) mod L advances by 8 l per step
+            int k = kc0 + 2 * kk + par;
+            int m = (int)(((int64_t)k * lrow) % L);
+            for (int js = 0; kc0 + 8 * js + par <= kend; js++, k += 8) {
+                const int kl = min(k - kc0, KCHQ - 1);          // rows past the chunk's last wavenumber hold zeros
+                const double2 t0 = twl[m];
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    const double bc = Cc[kl * CW + g * CSTP + i], bs = Cs[kl * CW + g * CSTP + i];
+                    P[g][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, P[g][par], 0, 0, 0);
+                    Q[g][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, Q[g][par], 0, 0, 0);
+                }
+                m += sm8;
+                if (m >= L) m -= L;
+            }
+        }
+    }
+    if (!rows) return;
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        if (i >= pgs.g[g].n) continue;
+        const int vv = pgs.g[g].v[i], sl = pgs.g[g].slot[i];
+        auto put = [&](int64_t pt, double val) {
+            if (sl == 0) phys.val[(int64_t)vv * N + pt] = val;
+            else phys.der[((int64_t)(sl - 1) * V + vv) * N + pt] = (ST)val;
+        };
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int lo = mt * 16 + kk + 4 * r;
+            if (lo > Lq) continue;
+            const double Ps = P[g][0][r] + P[g][1][r], Pd = P[g][0][r] - P[g][1][r], Qs = Q[g][0][r] + Q[g][1][r], Qd = Q[g][0][r] - Q[g][1][r];
+            put(p0 + lo, Ps - Qs);
+            if (lo > 0) put(p0 + (L - lo), Ps + Qs);
+            if (lo < Lq) {
+                put(p0 + (Lh - lo), Pd + Qd);
+                if (lo > 0) put(p0 + (Lh + lo), Pd - Qd);
+            }
+        }
+    }
+}
+
+// forward, RL grids: the quarter-wave fold of k_fl_forward_dft_q with the MFMA rows = the V variables of the ring; a workgroup takes
+// one PART of a ring's wavenumbers - wave w: parity w & 1, tile (w >> 1) + 4 part of 16 wavenumbers of that parity, i.e. 128
+// wavenumbers per workgroup - and folds the ring for itself.
+__global__ void __launch_bounds__(512)
+k_fl_forward_dft_qp(const double *__restrict__ np1, double *__restrict__ Fl, const int *__restrict__ Lr,
+                    const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
+                    const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
+                    int K2, int64_t N, const int *__restrict__ items, int lcap) {
+    extern __shared__ double sm[];
+    const int ring = items[2 * blockIdx.x], part = items[2 * blockIdx.x + 1];
+    const int L = Lr[ring], km = kmaxr[ring], Lh = L / 2, Lq = L / 4;
+    double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]
+    double *F = sm + 2 * (size_t)lcap;                          // [parity][cosine / sine part][LCQ][CST]
+    const double2 *phr = ph + phoff[ring];
+    const int64_t p0 = pstart[ring];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
+    const int n = lane & 15, kk = lane >> 4;
+    const int par = wave & 1, tq = (wave >> 1) + 4 * part;         // this wave's parity and tile
+    const int nk = km >= par ? (km - par) / 2 + 1 : 0;              // wavenumbers of this parity
+    const bool live = tq * 16 < nk;
+    dft_d4 ac = {0.0, 0.0, 0.0, 0.0}, as = ac;
+    const int kq = min(2 * (16 * tq + n) + par, km);                // this lane's B column (clamped: columns past km are dropped)
+    const int fourk = (int)(((int64_t)4 * kq) % L);
+    const double *x = np1 + p0;
+    const double *Fc = F + (size_t)(2 * par) * LCQ * CST, *Fs = Fc + (size_t)LCQ * CST;
+    for (int lc = 0; lc <= Lq; lc += LCQ) {
+        __syncthreads();
+        for (int o = tid; o < LCQ * DZC; o += blockDim.x) {
+            const int zz = o >> 6, r = o & (LCQ - 1), l = lc + r;       // ring points fastest across lanes: var_np1 is [v][point]
+            double ce = 0.0, se = 0.0, co = 0.0, so = 0.0;
+            if (zz < V && l <= Lq) {
+                const double *xv = x + (int64_t)zz * N;
+                const double a = xv[l];
+                if (l == 0) {
+                    const double c = xv[Lh];
+                    ce = a + c; co = a - c;
+                } else if (l == Lq) {
+                    const double b = xv[L - l];
+                    ce = a + b; so = a - b;
+                } else {
+                    const double b = xv[L - l], c = xv[Lh - l], d = xv[Lh + l];
+                    const double ab = a + b, cd = c + d, amb = a - b, dmc = d - c;
+                    ce = ab + cd; co = ab - cd; se = amb + dmc; so = amb - dmc;
+                }
+            }
+            F[(0 * LCQ + r) * CST + zz] = ce;
+            F[(1 * LCQ + r) * CST + zz] = se;
+            F[(2 * LCQ + r) * CST + zz] = co;
+            F[(3 * LCQ + r) * CST + zz] = so;
+        }
+        __syncthreads();
+        if (!live) continue;
+        const int ln4 = (min(LCQ, Lq + 1 - lc) + 3) & ~3;           // rows past Lq are staged as zeros
+        int m = (int)(((int64_t)kq * (lc + kk)) % L);
+        for (int ls = 0; ls < ln4; ls += 4) {
+            const double xc = Fc[(ls + kk) * CST + n], xs = Fs[(ls + kk) * CST + n];
+            const double2 t = twl[m];
+            ac = __builtin_amdgcn_mfma_f64_16x16x4f64(xc, t.x, ac, 0, 0, 0);
+            as = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, t.y, as, 0, 0, 0);
+            m += fourk;
+            if (m >= L) m -= L;
+        }
+    }
+    const int k = 2 * (16 * tq + n) + par;
+    if (!live || k > km) return;
+    const double inv = 1.0 / L;
+    const double2 w = phr[k];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int zz = kk + 4 * r;
+        if (zz >= V) continue;
+        const double sr = ac[r], si = -as[r];
+        double2 out;
+        if (k == 0) out = make_double2(sr * inv, 0.0);
+        else out = make_double2((sr * w.x + si * w.y) * inv, (si * w.x - sr * w.y) * inv);
+        *reinterpret_cast<double2 *>(Fl + ((int64_t)ring * V + zz) * K2 + 2 * k) = out;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 // grids without a vertical dimension: columns = (variable, plane)
 static bool dft_planes(const sx_handle *h) { return !h->has_z; }
@@ -716,6 +917,32 @@ static void for_ring_classes(sx_handle *h, int n_rings, F f, int max_classes = 4
     }
 }
 
+// (ring, part) work lists of the quarter-wave RL kernels, most expensive ring first: [0] inverse - a part is 8 row tiles of the
+// quarter ring (one per wave); [1] forward - a part is 128 wavenumbers (4 tiles of 16 per parity)
+static bool rlq_lists(sx_handle *h) {
+    if (h->d_rlq_items[0]) return true;
+    for (int which = 0; which < 2; which++) {
+        std::vector<std::array<int64_t, 3>> it;       // (cost, ring, part)
+        for (int r = 0; r < h->nrings; r++) {
+            const int tiles = h->hL[r] / 4 / 16 + 1;
+            const int parts = which == 0 ? (tiles + 7) / 8 : (h->hkmax[r] + 1 + 127) / 128;
+            for (int p = 0; p < parts; p++) it.push_back({(int64_t)h->hL[r], r, p});
+        }
+        std::stable_sort(it.begin(), it.end(), [](const auto &a, const auto &b) { return a[0] > b[0]; });
+        std::vector<int> flat;
+        for (const auto &e : it) { flat.push_back((int)e[1]); flat.push_back((int)e[2]); }
+        void *d = nullptr;
+        if (hipMalloc(&d, sizeof(int) * flat.size()) != hipSuccess || hipMemcpy(d, flat.data(), sizeof(int) * flat.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("RL work list upload failed");
+            return false;
+        }
+        h->allocs.push_back(d);
+        h->n_rlq_items[which] = (int)it.size();
+        h->d_rlq_items[which] = (int *)d;
+    }
+    return true;
+}
+
 static void launch_rl_inverse_dft_planes(sx_handle *h, bool full) {
     const std::vector<int> &mask = full ? h->hmask_full : h->hmask_eq;
     // kinds in slot order for RL grids: u, r, rr, l, ll  (slot[0..4])
@@ -737,6 +964,26 @@ static void launch_rl_inverse_dft_planes(sx_handle *h, bool full) {
     }
     if (pc.n > 0) push();                       // V <= 8 variables x 5 planes = 40 columns at most: 3 groups
     if (pgs.ng == 0) return;
+    if (h->rl_quarter && pgs.ng <= 3) {
+        // one launch over (ring, part) items, most expensive first; a part = 8 row tiles of the quarter ring (one per wave)
+        if (!rlq_lists(h)) return;
+        const double *a = h->d_A + (int64_t)h->cell0 * h->C;
+        const int lcap = h->L_max;
+#define DFT_INVQ(ST, NG)                                                                                                             \
+        {                                                                                                                            \
+            const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)2 * KCHQ * NG * CSTP);                                   \
+            auto kern = k_rl_inverse_dft_planes_q<ST, NG>;                                                                           \
+            HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(kern, dim3(h->n_rlq_items[0]), dim3(512), lds, h->stream, a, planes_of<ST>(h->d_phys, h->V, h->N),    \
+                               h->d_phi, h->d_L, h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->K2,      \
+                               h->nrings, h->N, h->C, pgs, h->d_rlq_items[0], lcap);                                                 \
+        }
+        if (h->f32) { if (pgs.ng == 1) DFT_INVQ(float, 1) else if (pgs.ng == 2) DFT_INVQ(float, 2) else DFT_INVQ(float, 3) }
+        else { if (pgs.ng == 1) DFT_INVQ(double, 1) else if (pgs.ng == 2) DFT_INVQ(double, 2) else DFT_INVQ(double, 3) }
+#undef DFT_INVQ
+        HIPCHK3(hipGetLastError());
+        return;
+    }
     const double *a = h->d_A + (int64_t)h->cell0 * h->C;
     // two launch classes only: each launch is as long as its largest ring's workgroup, so more classes mostly add tails
     for_ring_classes(h, h->nrings, [&](int r0, int nr, int lcap, int kcap) {
@@ -838,6 +1085,16 @@ void launch_fl_forward_dft(sx_handle *h) {
     timer_begin(h, id);
     const int planes = dft_planes(h) ? 1 : 0;
     static const bool half = getenv("SX_DFT_HALF") && atoi(getenv("SX_DFT_HALF")) != 0;      // A/B: the half-ring kernel
+    if (planes && h->rl_quarter && rlq_lists(h)) {      // RL grids: quarter-wave fold, one launch over (ring, part) items
+        const int lcap = h->L_max;
+        const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * LCQ * CST);
+        HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fl_forward_dft_qp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_fl_forward_dft_qp, dim3(h->n_rlq_items[1]), dim3(512), lds, h->stream, h->d_np1, h->d_Fl, h->d_L, h->d_kmax, h->d_pstart,
+                           h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->K2, h->N, h->d_rlq_items[1], lcap);
+        HIPCHK3(hipGetLastError());
+        timer_end(h);
+        return;
+    }
     if (!planes && !half) {          // quarter-wave form; 4 waves x NTW tiles x 16 = 192 wavenumbers per parity >= (kmax <= 319) / 2 + 1
         // ONE launch over the work list (four launches by ring size, each with its own tail: 0.32 -> 0.29 ms)
         // rings with kmax > 319 (listed first) in their own launch: the wavenumber tiles of a ring spread over gridDim.z

@@ -153,6 +153,9 @@ struct sx_handle {
     int n_dft_items[3] = {0, 0, 0};
     int n_dft_big[3] = {0, 0, 0};            // of which (listed first) rings with kmax > DFT_KMAX_SINGLE: chunked kernels
     int dft_lcap_small = 0, dft_kcap_small = 0;   // largest ring length / kmax among the other rings
+    int rl_quarter = 1;                      // RL grids: quarter-wave DFT kernels over one work list (SX_DFT_RLQ=0: the half-ring kernels in two ring classes)
+    int *d_rlq_items[2] = {nullptr, nullptr};    // (ring, part) items of the RL inverse / forward launch, most expensive first
+    int n_rlq_items[2] = {0, 0};
     // SX_DEFER_DIAG=1 (one-tile HRBL runs on the FFT path): the diagnostic variable w is written by the equation set before it is
     // read (src/shallowWaterModels.jl:69, 430), so its spline coefficients are consumed by OUTPUT only; sx_advance then sends
     // the five prognostic variables through the forward transform and the solve, and w's follow on demand (flush_diag) when
