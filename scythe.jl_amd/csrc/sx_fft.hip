@@ -169,6 +169,86 @@ __device__ __forceinline__ void fft_inplace(double2 *X, const Twiddles<LOGL, HL>
     }
 }
 
+// ------------------------------------------------------------------------------------------------ register-resident passes (L = 256)
+// Round 4.  The four radix-4 passes of a 256-point transform without LDS in between: decimation in frequency, element index =
+// (register q, lane); after each of the first three passes a 4 x 4 transpose between the register index and two lane bits brings
+// the next digit into the registers - lane bits 5 / 4 by v_permlane32_swap / v_permlane16_swap (gfx950: one instruction swaps a
+// dword both ways), bits 3 / 2 by DPP row_ror:8 / row_shl:4 + row_shr:4 under bank masks (one v_mov_dpp per dword), bits 1 / 0
+// by quad_perm + select.  profiles/micro/fft_exchange.hip (profiles/r04/micro_fft_exchange.txt): 1,145 cycles per transform and
+// wave against 2,850 through LDS (staging write and copy-out read included there), 1.8 x the transforms per second per CU.
+//   in:  v[q] = x[lane + 64 q]      out: v[q0] = X[l],  l = (lane >> 4) + 4 ((lane >> 2) & 3) + 16 (lane & 3) + 64 q0
+typedef unsigned int fft_u32;
+struct FftQ { fft_u32 d[4]; };          // one complex double as 4 dwords
+__device__ __forceinline__ FftQ fft_toq(double2 v) { return FftQ{{(fft_u32)__double2loint(v.x), (fft_u32)__double2hiint(v.x), (fft_u32)__double2loint(v.y), (fft_u32)__double2hiint(v.y)}}; }
+__device__ __forceinline__ double2 fft_fromq(const FftQ &q) { return make_double2(__hiloint2double((int)q.d[1], (int)q.d[0]), __hiloint2double((int)q.d[3], (int)q.d[2])); }
+
+// 2 x 2 step between the register pair (a: register bit clear, b: set) and lane bit BIT:
+//   lanes with the bit clear: b <- partner's a;   lanes with the bit set: a <- partner's b
+template <int BIT>
+__device__ __forceinline__ void fft_swap2(double2 &a, double2 &b, int lane) {
+    FftQ A = fft_toq(a), B = fft_toq(b);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (BIT == 5) {
+            const auto r = __builtin_amdgcn_permlane32_swap(A.d[i], B.d[i], false, false);     // A[32..63] <-> B[0..31]
+            A.d[i] = r[0]; B.d[i] = r[1];
+        } else if (BIT == 4) {
+            const auto r = __builtin_amdgcn_permlane16_swap(A.d[i], B.d[i], false, false);     // A[odd rows of 16] <-> B[even rows]
+            A.d[i] = r[0]; B.d[i] = r[1];
+        } else if (BIT == 3) {           // row_ror:8 = lane ^ 8 within a row of 16; banks 0, 1 = lanes 0-7 of the row
+            const fft_u32 nb = __builtin_amdgcn_update_dpp(B.d[i], A.d[i], 0x128, 0xF, 0x3, false);
+            const fft_u32 na = __builtin_amdgcn_update_dpp(A.d[i], B.d[i], 0x128, 0xF, 0xC, false);
+            A.d[i] = na; B.d[i] = nb;
+        } else if (BIT == 2) {           // banks 0, 2 (bit 2 clear) read lane + 4 (row_shl:4), banks 1, 3 read lane - 4 (row_shr:4)
+            const fft_u32 nb = __builtin_amdgcn_update_dpp(B.d[i], A.d[i], 0x104, 0xF, 0x5, false);
+            const fft_u32 na = __builtin_amdgcn_update_dpp(A.d[i], B.d[i], 0x114, 0xF, 0xA, false);
+            A.d[i] = na; B.d[i] = nb;
+        } else {                         // quad_perm: lane ^ 2 = [2,3,0,1] (0x4E), lane ^ 1 = [1,0,3,2] (0xB1)
+            constexpr int ctl = BIT == 1 ? 0x4E : 0xB1;
+            const fft_u32 pa = __builtin_amdgcn_mov_dpp(A.d[i], ctl, 0xF, 0xF, false);
+            const fft_u32 pb = __builtin_amdgcn_mov_dpp(B.d[i], ctl, 0xF, 0xF, false);
+            const bool set = (lane >> BIT) & 1;
+            const fft_u32 na = set ? pb : A.d[i], nb = set ? B.d[i] : pa;
+            A.d[i] = na; B.d[i] = nb;
+        }
+    }
+    a = fft_fromq(A); b = fft_fromq(B);
+}
+// 4 x 4 transpose: register bit 1 <-> lane bit HI, register bit 0 <-> lane bit HI - 1
+template <int HI>
+__device__ __forceinline__ void fft_transpose4(double2 (&v)[4], int lane) {
+    fft_swap2<HI>(v[0], v[2], lane); fft_swap2<HI>(v[1], v[3], lane);
+    fft_swap2<HI - 1>(v[0], v[1], lane); fft_swap2<HI - 1>(v[2], v[3], lane);
+}
+// decimation-in-frequency radix-4 butterfly, inverse sign: y_q = (sum_p a_p i^{pq}) w^q
+__device__ __forceinline__ void fft_bfly_dif(double2 (&v)[4], double2 w1, bool tw) {
+    const double2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]), t2 = cadd(v[1], v[3]), t3 = cmuli(csub(v[1], v[3]), +1);
+    const double2 y0 = cadd(t0, t2);
+    double2 y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+    if (tw) {
+        const double2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
+        y1 = cmul(y1, w1); y2 = cmul(y2, w2); y3 = cmul(y3, w3);
+    }
+    v[0] = y0; v[1] = y1; v[2] = y2; v[3] = y3;
+}
+// w[0] = e^{+2 pi i lane / 256}, w[1] = e^{+2 pi i (lane & 15) / 64}, w[2] = e^{+2 pi i (lane & 3) / 16}
+__device__ __forceinline__ void fft_reg256_inverse(double2 (&v)[4], const double2 (&w)[3], int lane) {
+    fft_bfly_dif(v, w[0], true);
+    fft_transpose4<5>(v, lane);
+    fft_bfly_dif(v, w[1], true);
+    fft_transpose4<3>(v, lane);
+    fft_bfly_dif(v, w[2], true);
+    fft_transpose4<1>(v, lane);
+    fft_bfly_dif(v, w[0], false);
+}
+__device__ __forceinline__ double2 fft_bpermute(double2 v, int src_lane) {
+    const FftQ q = fft_toq(v);
+    FftQ r;
+#pragma unroll
+    for (int i = 0; i < 4; i++) r.d[i] = (fft_u32)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)q.d[i]);
+    return fft_fromq(r);
+}
+
 // ------------------------------------------------------------------------------------------------ inverse
 // The output planes are `physical` or the node-space array G: value slot fp64, derivative slots ST (Planes, sx_internal.hpp)
 // (Re, Im) pair of a spectral intermediate stored as fp64 or fp32 (storage_f32 = 2), widened on load
@@ -187,7 +267,7 @@ __device__ __forceinline__ void stpair(float *p, double2 v) { *reinterpret_cast<
 // column tiles of 16 wavenumber blocks, operands straight from L2), through the LDS set the next slot is about to stage,
 // into the lanes' registers; `Az` of the node-space units is never written or read (k_zinv then only serves the ring-wise rings).
 typedef double fft_d4 __attribute__((ext_vector_type(4)));
-template <int LOGL, int COPYOUT, bool NODE, class ST, class AT = double, int HL = 0, int SETS = 2, bool FUSE = false>
+template <int LOGL, int COPYOUT, bool NODE, class ST, class AT = double, int HL = 0, int SETS = 2, bool FUSE = false, bool REG = false>
 __global__ void __launch_bounds__(512 >> HL, HL ? 3 : (LOGL <= 8 || SETS == 1) ? 4 : 2)      // waves per SIMD: at L = 512 one workgroup per CU with two LDS sets (2 x 64 KB, 4 wavenumbers per lane), two with one set
 k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi,
                  const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const double2 *__restrict__ twg,
@@ -199,7 +279,11 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
     // NODE: the "rings" are radial NODES (uniform ring tables only): one Az row per unit, no radial combination;
     // the output is the node-space array G that the equation-set kernel combines with the basis weights itself.
     constexpr int L = 1 << LOGL, T = FftCfg<LOGL, HL>::LPT, NK = FftCfg<LOGL, HL>::NK;
-    constexpr int FZC = FftCfg<LOGL, HL>::FZC, FNP = FftCfg<LOGL, HL>::FNP, LOGZ = FftCfg<LOGL, HL>::LOGZ, SKEW = FftCfg<LOGL, HL>::SKEW;
+    constexpr int FZC = FftCfg<LOGL, HL>::FZC, FNP = FftCfg<LOGL, HL>::FNP, LOGZ = FftCfg<LOGL, HL>::LOGZ;
+    // REG: the transform's LDS region only serves the copy-out; ring point l sits at l + (l >> 4), so that the 16 lanes of a row -
+    // points 4 a + 16 b after the last register pass - fall into 16 different 16-byte bank groups (stride = 2 mod 16 for the readers)
+    constexpr int SKEW = REG ? 18 : FftCfg<LOGL, HL>::SKEW;
+    static_assert(!REG || (LOGL == 8 && HL == 0 && COPYOUT && !FUSE), "register-resident passes: 256-point transforms with copy-out");
     extern __shared__ double2 smf[];
     FFT_STAMP(0);
     int nslot = 0;
@@ -338,7 +422,14 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                     int tt = t;
                     asm volatile("" : "+v"(tt));               // opaque copy: the table addresses are formed HERE (hoisted out of the
                                                                // group loop they were spilled, and every reload drained the memory counter)
-                    tw.template init<+1>(twg, tt);
+                    if (REG) {
+                        // twiddles of the three register passes: kept in LDS behind the copy-out sets (3 KB, the same for every wave - each
+                        // wave writes the whole table and reads back its own writes, no workgroup barrier), not in 12 registers: at the 128
+                        // registers of a two-workgroups-per-CU kernel they cost a spilled address, and every reload of it drained the
+                        // memory counter - i.e. waited for the previous slot's copy-out stores
+                        double2 *wl = smf + SETS * FNP * (L + SKEW);
+                        wl[tt] = twg[tt]; wl[64 + tt] = twg[4 * (tt & 15)]; wl[128 + tt] = twg[16 * (tt & 3)];
+                    } else tw.template init<+1>(twg, tt);
                     if (!NODE) {
 #pragma unroll
                         for (int q = 0; q < NK; q++) if (inq[q]) phq[q] = phr[tt + q * T];
@@ -367,6 +458,33 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
             double2 *X = set + f * (L + SKEW);
             par ^= 1;
             if (COPYOUT && SETS == 1 && nslot > 0) lds_barrier();     // the previous slot's copy-out has read this (only) set
+            if constexpr (REG) {
+                // packed spectrum W = Za + i Zb of this lane's wavenumbers k = t, t + 64 and of their mirrors L - k
+                double2 wk[2], mir[2];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int k = kq[q];
+                    double2 c = aq[q], e = bq[q];
+                    if (ld == 1) { c = make_double2(-k * aq[q].y, k * aq[q].x); e = make_double2(-k * bq[q].y, k * bq[q].x); }
+                    else if (ld == 2) { const double qq = -(double)k * k; c.x *= qq; c.y *= qq; e.x *= qq; e.y *= qq; }
+                    wk[q] = make_double2(c.x - e.y, c.y + e.x);
+                    mir[q] = k > 0 ? make_double2(c.x + e.y, e.x - c.y) : make_double2(0.0, 0.0);      // k = 0: the Nyquist bin, zero
+                }
+                // x[t + 128] = W[L - (128 - t)] and x[t + 192] = W[L - (64 - t)] are the mirrors lane 64 - t holds (its second / first
+                // wavenumber); lane 0 keeps its own: x[128] = 0 (Nyquist), x[192] = W[L - 64]
+                const int src = (64 - t) & 63;
+                const double2 r0 = fft_bpermute(mir[0], src), r1 = fft_bpermute(mir[1], src);
+                double2 v[4] = {wk[0], wk[1], t == 0 ? r0 : r1, t == 0 ? r1 : r0};
+                const double2 *wl = smf + SETS * FNP * (L + SKEW);
+                const double2 wreg[3] = {wl[t], wl[64 + t], wl[128 + t]};
+                fft_reg256_inverse(v, wreg, t);
+                if (nslot == 0) FFT_STAMP(2); else if (nslot == 1) FFT_STAMP(5);
+                const int lb = (t >> 4) + 4 * ((t >> 2) & 3) + 16 * (t & 3);
+                if (active) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const int l = lb + 64 * q; X[l + (l >> 4)] = v[q]; }
+                }
+            } else
             if (active) {
 #pragma unroll
                 for (int q = 0; q < NK; q++) {
@@ -384,11 +502,13 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                     else X[L / 2] = make_double2(0.0, 0.0);
                 }
             }
-            wave_sync();
+            if (!REG) wave_sync();
             if (COPYOUT) {
                 // last pass goes back to LDS, then the whole workgroup writes full 128-byte lines
-                fft_inplace<LOGL, +1, true, NoSink, HL>(X, tw, t, active);
-                if (nslot == 0) FFT_STAMP(2); else if (nslot == 1) FFT_STAMP(5);
+                if constexpr (!REG) {
+                    fft_inplace<LOGL, +1, true, NoSink, HL>(X, tw, t, active);
+                    if (nslot == 0) FFT_STAMP(2); else if (nslot == 1) FFT_STAMP(5);
+                }
                 lds_barrier();       // also orders the previous slot's copy-out reads (other set) before that set is restaged
                 if (nslot == 0) FFT_STAMP(3);
                 // thread -> (level pair zp, ring point l0 + (2 * 512 / FZC) i): a transform's LDS element l IS the pair of levels
@@ -403,7 +523,7 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                     if (pair_ok && 2 * zp + 1 < zc) {
 #pragma unroll 4
                         for (int l = threadIdx.x >> (LOGZ - 1); l < L; l += (int)(blockDim.x >> (LOGZ - 1))) {
-                            const double2 y = src2[l];
+                            const double2 y = src2[REG ? l + (l >> 4) : l];
                             ov2 o2;
                             o2.x = (OT)y.x; o2.y = (OT)y.y;
                             __builtin_nontemporal_store(o2, reinterpret_cast<ov2 *>(out + (int64_t)l * nz + 2 * zp));
@@ -411,7 +531,7 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                     } else if (2 * zp < zc) {      // odd zDim (pairs not 16-byte aligned) or the last level of an odd chunk
                         const bool two = 2 * zp + 1 < zc;
                         for (int l = threadIdx.x >> (LOGZ - 1); l < L; l += (int)(blockDim.x >> (LOGZ - 1))) {
-                            const double2 y = src2[l];
+                            const double2 y = src2[REG ? l + (l >> 4) : l];
                             __builtin_nontemporal_store((OT)y.x, out + (int64_t)l * nz + 2 * zp);
                             if (two) __builtin_nontemporal_store((OT)y.y, out + (int64_t)l * nz + 2 * zp + 1);
                         }
@@ -546,7 +666,7 @@ bool fft_fused_zinv(const sx_handle *h) {
 }
 
 static int fft_fzc(int) { return 16; }
-static size_t fft_lds(int L, int sets = 1) { return sizeof(double2) * (size_t)sets * (fft_fzc(L) / 2) * (L + (L <= 256 ? 2 : 0)); }
+static size_t fft_lds(int L, int sets = 1, bool reg = false) { return sizeof(double2) * ((size_t)sets * (fft_fzc(L) / 2) * (L + (reg ? 18 : L <= 256 ? 2 : 0)) + (reg ? 192 : 0)); }
 static int fft_threads(int L, int hl = 0) { return std::max(64, (fft_fzc(L) / 2) * (std::min(L / 4, 64) >> hl)); }       // FNP transforms x LPT lanes
 
 struct InvTarget {          // where an inverse ring launch writes and which unit tables it uses
@@ -575,7 +695,23 @@ static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, con
                            h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6], nullptr, (int64_t)0, nullptr, 0,  \
                            tg.unit0);                                                                                                \
     } while (0)
-#define INV_LAUNCH(NODE, ST, AT) INV_LAUNCH_V(NODE, ST, AT, 0, 2)
+#define INV_LAUNCH_REG(NODE, ST, AT)                                                                                                 \
+    do {                                                                                                                             \
+        constexpr int RS = 2;                                                                                                        \
+        if (fft_lds(L, RS, true) > 65536)                                                                                            \
+            HIPCHK2(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rl_inverse_fft<LOGL, 1, NODE, ST, AT, 0, RS, false, true>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)fft_lds(L, RS, true)));                    \
+        hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, NODE, ST, AT, 0, RS, false, true>), g, dim3(fft_threads(L, 0)), fft_lds(L, RS, true), h->stream, \
+                           reinterpret_cast<const AT *>(az), planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart,          \
+                           h->d_tw, tg.phoff, h->d_ph, d_mask, h->V, h->nz, h->nsz, h->K2, tg.n_phi, tg.N, azrow, h->slot[0],        \
+                           h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], h->slot[6], nullptr, (int64_t)0, nullptr, 0,  \
+                           tg.unit0);                                                                                                \
+    } while (0)
+#define INV_LAUNCH(NODE, ST, AT)                                                                                                     \
+    do {                                                                                                                             \
+        if constexpr (LOGL == 8) { if (h->fft_reg) { INV_LAUNCH_REG(NODE, ST, AT); break; } }                                        \
+        INV_LAUNCH_V(NODE, ST, AT, 0, 2);                                                                                            \
+    } while (0)
 #define INV_LAUNCH_FUSED(ST)                                                                                                         \
     hipLaunchKernelGGL((k_rl_inverse_fft<LOGL, 1, true, ST, double, 0, 2, true>), g, dim3(fft_threads(L)), fft_lds(L, 2), h->stream,  \
                        az, planes_of<ST>(tg.out, h->V, tg.N), tg.phi, tg.kmax, tg.pstart, h->d_tw, tg.phoff, h->d_ph, d_mask, h->V,   \
@@ -587,6 +723,7 @@ static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, con
     else { if (tg.node_mode) INV_LAUNCH(true, double, double); else INV_LAUNCH(false, double, double); }
 #undef INV_LAUNCH_FUSED
 #undef INV_LAUNCH
+#undef INV_LAUNCH_REG
 #undef INV_LAUNCH_V
 }
 

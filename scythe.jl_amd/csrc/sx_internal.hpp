@@ -153,6 +153,7 @@ struct sx_handle {
     int n_dft_items[3] = {0, 0, 0};
     int n_dft_big[3] = {0, 0, 0};            // of which (listed first) rings with kmax > DFT_KMAX_SINGLE: chunked kernels
     int dft_lcap_small = 0, dft_kcap_small = 0;   // largest ring length / kmax among the other rings
+    int fft_reg = 1;                         // 256-point inverse transforms: register-resident passes with lane swaps (SX_FFT_REG=0: every pass through LDS)
     int rl_quarter = 1;                      // RL grids: quarter-wave DFT kernels over one work list (SX_DFT_RLQ=0: the half-ring kernels in two ring classes)
     int *d_rlq_items[2] = {nullptr, nullptr};    // (ring, part) items of the RL inverse / forward launch, most expensive first
     int n_rlq_items[2] = {0, 0};
