@@ -505,7 +505,15 @@ def main():
 
     serial = None
     if run_ov is not None:
-        # ---- THE timed region: exactly K steps of the two-stream schedule, no event on any stream
+        # ---- the serial pass FIRST: K steps on one stream with the dominant kernel's event pair -> roofline (and the device stays busy)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run.step()
+        barrier()
+        el_serial = time.perf_counter() - t0
+        serial = {"steps_per_s": args.steps / el_serial, "ms_per_step": 1e3 * el_serial / args.steps, "steps": args.steps,
+                  "note": "one stream, the dominant kernel's hipEvent pair on it: the pass `roofline` is measured in (it runs before the timed region)"}
+        # ---- THE timed region: W warm-up steps, then exactly K steps of the two-stream schedule, no event on any stream
         for _ in range(args.warmup):
             run_ov.step()
         barrier()
@@ -514,16 +522,7 @@ def main():
             run_ov.step()
         barrier()
         elapsed = time.perf_counter() - t0
-        nan = run_ov.tiles[0].check_nan()
-        # ---- the serial pass: the same K steps on one stream with the dominant kernel's event pair -> roofline
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run.step()
-        barrier()
-        el_serial = time.perf_counter() - t0
-        serial = {"steps_per_s": args.steps / el_serial, "ms_per_step": 1e3 * el_serial / args.steps, "steps": args.steps,
-                  "note": "one stream, the dominant kernel's hipEvent pair on it: the pass `roofline` is measured in"}
-        nan = bool(nan) or bool(tile.check_nan())
+        nan = bool(run_ov.tiles[0].check_nan()) or bool(tile.check_nan())
     else:
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -587,14 +586,14 @@ def main():
                                     "bit-identical fields" if run_ov is not None else "one stream"),
                        # what ran on the device right before the W warm-up steps (from an idle GPU the first ~25 steps of
                        # any run are up to 18 % slow)
-                       "device_busy_before_warmup": ("native_equivalent run" if native is not None else
+                       "device_busy_before_warmup": ("native_equivalent run, then the serial roofline pass" if (native is not None and serial is not None) else "native_equivalent run" if native is not None else
                                                      "self-check's torch.distributed run, 100 steps" if preheat is not None else "nothing (cold start)"),
                        "ts": TS_OF.get(args.workload, TS), "nan": bool(nan),
                        "parity": PARITY_CLAIM if args.storage == "f64" else "declared tolerance of the fp32-storage mode: values 1e-6, derivative slots 5e-5 (DESIGN.md 3)"},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "measured_in": ("the serial pass (serial_schedule), %d steps" % args.steps if serial is not None else "the timed region"),
+                         "measured_in": ("the serial pass (serial_schedule), %d steps, run right before the timed region" % args.steps if serial is not None else "the timed region"),
                          "achievable_peak": HBM_ACHIEVABLE_GBS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBS,
                          # whole step: PMC bytes of every kernel of a step / step time (null without matching PMC passes)
                          "step_traffic": step_traffic,
