@@ -125,6 +125,122 @@ k_rz_inverse(const double *__restrict__ Arows /* tile rows [nbt][C] */, Planes<S
     }
 }
 
+// Vertical transform FIRST, on the spline NODES (one third as many as rings): workgroup = (13 cells = the 16 nodes they touch, variable,
+// group of 4 level tiles).  The A rows of the 16 nodes go to LDS ([zm][node]); each wave takes one tile of 16 levels and forms
+// Az[sz][node][level] = M_sz A for the <= 3 operators the mask asks for (one LDS operand, three operator fragments: 3 MFMAs per LDS
+// read); the result goes back to LDS and the same wave evaluates the 39 rings of the 13 cells from it - 4-term sums with the basis
+// weights, value / d/dr / d2/dr2 from the "value" operator, d/dz and d2/dz2 from the other two - writing 128-byte level runs.
+// 96 instead of 160 MFMAs per wave and a third of the workgroups of the ring-tile form above (k_rz_inverse, kept for SX_RZ_INV=0).
+constexpr int RZ_CT = RZ_T - 3;       // cells per workgroup: their rings need nodes c .. c + 3, i.e. 16 nodes in all
+
+template <int NB, int KC>
+__device__ __forceinline__ void rz_ops_pass(const double *__restrict__ sa, const double *const (&op)[3], int64_t rs, int nrows, int nchunks,
+                                            int lane, int kk, rz_d4 (&acc)[3]) {
+#pragma unroll
+    for (int a = 0; a < NB; a++) acc[a] = rz_d4{0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < nchunks; c++) {
+        double b[NB][KC];
+#pragma unroll
+        for (int q = 0; q < KC; q++)
+#pragma unroll
+            for (int a = 0; a < NB; a++) b[a][q] = op[a][(int64_t)min(4 * (c * KC + q) + kk, nrows - 1) * rs];      // rows beyond nrows meet zeros
+#pragma unroll
+        for (int q = 0; q < KC; q++) {
+            const double av = sa[(4 * (c * KC + q)) * RZ_T + lane];
+#pragma unroll
+            for (int a = 0; a < NB; a++) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[a][q], acc[a], 0, 0, 0);
+        }
+    }
+}
+
+template <class ST>
+__global__ void __launch_bounds__(256)
+k_rz_inverse_nodes(const double *__restrict__ Arows /* tile rows [nbt][C] */, Planes<ST> phys, const double *__restrict__ phi /* [3][nrings][4] */,
+                   const double *__restrict__ MzT /* [v][sz][Zb][nz] */, const int *__restrict__ slotmask, int V, int nz, int Zb, int ncells,
+                   int nbt, int64_t N, int64_t C, int s_u, int s_r, int s_rr, int s_z, int s_zz) {
+    extern __shared__ double sm[];
+    const int c0 = blockIdx.x * RZ_CT, v = blockIdx.y;   // first cell = first node of the workgroup
+    const int mask = slotmask[v];
+    const bool n_u = (mask >> s_u) & 1, n_r = (mask >> s_r) & 1, n_rr = (mask >> s_rr) & 1, n_z = (mask >> s_z) & 1, n_zz = (mask >> s_zz) & 1;
+    if (!(n_u || n_r || n_rr || n_z || n_zz)) return;
+    constexpr int KC = 8, CH = 4 * KC, ZS = 65;          // Az row stride: 64 levels per workgroup + 1
+    const int Zp = (Zb + CH - 1) / CH * CH, nchunks = Zp / CH;
+    const int nrings = ncells * MUBAR;
+    double *sA = sm;                                     // [Zp][16]          A rows of the 16 nodes, zero beyond b_zDim / the tile
+    double *sAz = sA + (size_t)Zp * RZ_T;                // [3][16][ZS]       vertically transformed node values of this workgroup's 64 levels
+    double *sphi = sAz + (size_t)3 * RZ_T * ZS;          // [3][39][4]        basis weights of the 39 rings
+    {
+        const int nl = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+        const int node = min(c0 + nl, nbt - 1);
+        const double nlive = c0 + nl < nbt ? 1.0 : 0.0;
+        const double *a = Arows + (int64_t)node * C + (int64_t)v * Zb;
+#pragma unroll 4
+        for (int zm = l16; zm < Zp; zm += 16) sA[zm * RZ_T + nl] = (zm < Zb ? nlive : 0.0) * a[min(zm, Zb - 1)];
+    }
+    for (int e = threadIdx.x; e < 3 * RZ_CT * MUBAR * 4; e += blockDim.x) {
+        const int j = e & 3, rl = (e >> 2) % (RZ_CT * MUBAR), d = (e >> 2) / (RZ_CT * MUBAR);
+        const int ring = min(c0 * MUBAR + rl, nrings - 1);
+        sphi[e] = phi[((int64_t)d * nrings + ring) * 4 + j];
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n16 = lane & 15, kk = lane >> 4;
+    const int nzt = (nz + 15) / 16;
+    const int zt = blockIdx.z * 4 + wave;                // this wave's tile of 16 levels
+    if (zt >= nzt) return;
+    const int z = zt * 16 + n16;
+    const bool zok = z < nz;
+    const int zc = min(z, nz - 1);
+    // operators this variable needs: sz = 0 (value, for u / r / rr), 1 (d/dz), 2 (d2/dz2)
+    int szs[3], nb = 0;
+    if (n_u || n_r || n_rr) szs[nb++] = 0;
+    if (n_z) szs[nb++] = 1;
+    if (n_zz) szs[nb++] = 2;
+    for (int a = nb; a < 3; a++) szs[a] = szs[0];
+    const double *const ops[3] = {MzT + ((int64_t)v * 3 + szs[0]) * Zb * nz + zc, MzT + ((int64_t)v * 3 + szs[1]) * Zb * nz + zc,
+                                  MzT + ((int64_t)v * 3 + szs[2]) * Zb * nz + zc};
+    rz_d4 acc[3];
+    if (nb == 3) rz_ops_pass<3, KC>(sA, ops, nz, Zb, nchunks, lane, kk, acc);
+    else if (nb == 2) rz_ops_pass<2, KC>(sA, ops, nz, Zb, nchunks, lane, kk, acc);
+    else rz_ops_pass<1, KC>(sA, ops, nz, Zb, nchunks, lane, kk, acc);
+    // D[m = node kk + 4 r][n = level]: into this wave's 16 columns of the Az tile
+    for (int a = 0; a < nb; a++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) sAz[(szs[a] * RZ_T + kk + 4 * r) * ZS + wave * 16 + n16] = acc[a][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the 39 rings of the 13 cells: lane = (ring sub-index kk, level n16); 16 consecutive levels of a ring = one 128-byte run
+    const int zl = wave * 16 + n16;
+    for (int rl = kk; rl < RZ_CT * MUBAR; rl += 4) {
+        const int ring = c0 * MUBAR + rl;
+        if (ring >= nrings) break;
+        const int cl = rl / MUBAR;                       // local cell = first of its 4 nodes
+        const int64_t pt = (int64_t)ring * nz + z;
+        auto put = [&](int slot, double val) {
+            if (!zok) return;
+            if (slot == 0) phys.val[(int64_t)v * N + pt] = val;
+            else phys.der[((int64_t)(slot - 1) * V + v) * N + pt] = (ST)val;
+        };
+        if (n_u || n_r || n_rr) {
+            const double *g = sAz + (size_t)(0 * RZ_T + cl) * ZS + zl;
+            const double g0 = g[0], g1 = g[ZS], g2 = g[2 * ZS], g3 = g[3 * ZS];
+            const double *p0 = sphi + (size_t)rl * 4, *p1 = p0 + RZ_CT * MUBAR * 4, *p2 = p1 + RZ_CT * MUBAR * 4;
+            if (n_u) put(s_u, p0[0] * g0 + p0[1] * g1 + p0[2] * g2 + p0[3] * g3);
+            if (n_r) put(s_r, p1[0] * g0 + p1[1] * g1 + p1[2] * g2 + p1[3] * g3);
+            if (n_rr) put(s_rr, p2[0] * g0 + p2[1] * g1 + p2[2] * g2 + p2[3] * g3);
+        }
+        if (n_z || n_zz) {
+            const double *p0 = sphi + (size_t)rl * 4;
+#pragma unroll
+            for (int sz = 1; sz < 3; sz++) {
+                if (!(sz == 1 ? n_z : n_zz)) continue;
+                const double *g = sAz + (size_t)(sz * RZ_T + cl) * ZS + zl;
+                put(sz == 1 ? s_z : s_zz, p0[0] * g[0] + p0[1] * g[ZS] + p0[2] * g[2 * ZS] + p0[3] * g[3 * ZS]);
+            }
+        }
+    }
+}
+
 // Radial inner products of 16 nodes: the weights wq * phi0 of the 19 cells (57 rings) that touch them go to LDS first (zero for
 // cells outside the tile), then a thread walks the 11 cells (33 rings) of its half of the nodes for ONE level - 33 loads requested
 // together - and keeps the 8 node sums in registers.
@@ -307,6 +423,22 @@ bool rz_fused(const sx_handle *h) { return h->rz_fused && h->geom == SX_GEOM_RZ 
 void launch_rz_inverse(sx_handle *h, const int *d_mask) {
     const int id = timer_id(h, "k_rz_inverse");
     timer_begin(h, id);
+    static const bool by_nodes = !(getenv("SX_RZ_INV") && atoi(getenv("SX_RZ_INV")) == 0);      // A/B: 0 = the ring-tile form
+    if (by_nodes) {
+        const int Zpn = (h->Zb + 31) / 32 * 32;
+        dim3 gn((h->ncells + RZ_CT - 1) / RZ_CT, h->V, ((h->nz + 15) / 16 + 3) / 4);
+        const size_t ldsn = sizeof(double) * ((size_t)Zpn * RZ_T + 3 * RZ_T * 65 + 3 * RZ_CT * MUBAR * 4);
+        const double *arows = h->d_A + (int64_t)h->cell0 * h->C;
+#define RZ_INVN(ST) hipLaunchKernelGGL(k_rz_inverse_nodes<ST>, gn, dim3(256), ldsn, h->stream, arows, planes_of<ST>(h->d_phys, h->V, h->N), h->d_phi, h->d_MzT, \
+                                       d_mask, h->V, h->nz, h->Zb, h->ncells, h->nbt, h->N, h->C, h->slot[0], h->slot[1], h->slot[2], h->slot[5], h->slot[6])
+        if (ldsn <= 65536) {
+            if (h->f32) RZ_INVN(float); else RZ_INVN(double);
+            HIPCHK4(hipGetLastError());
+            timer_end(h);
+            return;
+        }
+#undef RZ_INVN
+    }
     const int Zp = (h->Zb + 4 * RZ_KC - 1) / (4 * RZ_KC) * (4 * RZ_KC);
     dim3 g((h->nrings + RZ_T - 1) / RZ_T, h->V, ((h->nz + 15) / 16 + 3) / 4);
     const size_t lds = sizeof(double) * 3 * Zp * RZ_T;

@@ -339,7 +339,8 @@ def test_semi_implicit_adjustment_on_the_matrix_cores_equals_the_scalar_kernel(m
         # (two summation orders of operators whose norm grows as zDim^4)
         assert np.abs(fa[:, v] - fb[:, v]).max() <= 1e-12 * max(1.0, (zDim / 64.0) ** 4) * max(np.abs(fb[:, v]).max(), 1e-300), v
     pa, po = a.physical(), orc.physical()
-    assert cases.rel_err_per_var(pa[:, :, :1], po[:, :, :1]) < TOL          # the model fields
+    # the model fields (beyond 128 levels the column operators' O(zDim^4) norms put two correct fp64 runs further apart than 1e-10)
+    assert cases.rel_err_per_var(pa[:, :, :1], po[:, :, :1]) < TOL * max(1.0, (zDim / 128.0) ** 4)
     if zDim <= 33:          # (beyond that the d2/dz2 slot of two fp64 runs differs by N^4 eps: tests/test_gpu_configs.py treats config 3)
         assert cases.rel_err_per_var(pa, po) < TOL
 
