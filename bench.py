@@ -443,9 +443,11 @@ def main():
     run_ov = None
     if world == 1 and args.schedule == "overlap" and args.storage == "f64":
         run_ov = make_run("torch", overlap=True)
-        if not (run_ov.tiles[0].dims.n_points == tile.dims.n_points):
-            run_ov.close()
-            run_ov = None
+        # first-use costs of the second stream (its creation, the fork / join events, the first launches behind them: 200 us of host
+        # time per step over the first steps, profiles/r04/overlap_steps.txt) are set-up, not throughput: 10 steps here, before anything is timed
+        for _ in range(10):
+            run_ov.step()
+        torch.cuda.synchronize()
 
     # The same model on Springsteel's NATIVE ragged rings (SURVEY.md 8(d) "native-equivalent shape": 85 cells -> 255 rings of
     # 4 + 4 ri points, 131,580 horizontal points x 64 levels): the layout a drop-in must run; its azimuthal transforms are dense

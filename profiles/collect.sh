@@ -5,10 +5,10 @@
 # 5) the un-profiled default bench line.  Results land under gpurun_out/prof/<round>/ and are copied from there into
 # profiles/<round>/ (see profiles/README.md).
 set -e
-ROUND=${1:-r03}; TAG=${2:-v1}
+ROUND=${1:-r04}; TAG=${2:-v1}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof/$ROUND; mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-native"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-native --no-other-configs --schedule serial"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o $TAG -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/stats.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o fetch -- $BENCH > /dev/null 2> $OUT/fetch.log
