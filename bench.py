@@ -43,6 +43,7 @@ WORKLOADS = {
 # BASELINE.json configs 2 and 3 (bench_configs.py; one GPU, not the headline): reported under "other_configs" of the headline
 # line, or as the line's own workload with --workload
 OTHER_WORKLOADS = {
+    "r_linear_advection_1d": "config1_r",      # models/LinearAdvection1D.jl (the reference's own CPU-runnable case: plumbing, launch-bound here)
     "rl_cha_bell2024": "config2_literal",      # models/cha_bell2024/Oneway_ShallowWater_Slab.jl:1-40, 100 cells, native rings
     "rz_513x128_semi": "config3_rz",           # RZ 513 x 128, Chebyshev vertical + semiimplicit_adjustment (src/semiimplicit.jl:521-597)
 }
@@ -266,16 +267,38 @@ def time_other_config(S, torch, dev, name, steps, warmup, graph=None):
         run.step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    # the same steps replayed from hipGraphs (sx_step with SX_GRAPH=1: one graph launch per step; bit-identical fields)
+    graph = None
+    try:
+        os.environ["SX_GRAPH"] = "1"
+        rung = S.ModelRun(mp, num_tiles=1, device=dev)
+        os.environ.pop("SX_GRAPH", None)
+        rung.set_initial_conditions([case["ic"](pts.reshape(len(pts), -1))])
+        for _ in range(20):
+            rung.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rung.step()
+        torch.cuda.synchronize()
+        dtg = (time.perf_counter() - t0) / steps
+        graph = {"steps_per_s": 1.0 / dtg, "ms_per_step": 1e3 * dtg, "nan": bool(rung.tiles[0].check_nan()),
+                 "note": "sx_step with SX_GRAPH=1: one hipGraph launch per step instead of one launch per kernel"}
+        rung.close()
+    except Exception as e:
+        os.environ.pop("SX_GRAPH", None)
+        graph = {"steps_per_s": None, "error": repr(e)[:200]}
     rows = kernel_table(tile, per_step, launches, load_pmc(S, name))
     dom = max(per_step.items(), key=lambda kv: kv[1])[0] if per_step else None
     d = tile.dims
     # SURVEY.md 8(d)'s fixed byte model of a step: B_step = 8 V [N (2 D + 5) + 4 S]
     b_step = 8.0 * d.n_vars * (d.n_points * (2 * d.n_derivs + 5) + 4 * d.s_patch)
-    out = {"workload": {"rl_cha_bell2024": "RL two-layer shallow-water slab, models/cha_bell2024/Oneway_ShallowWater_Slab.jl verbatim: 100 cells -> 300 native "
+    out = {"workload": {"r_linear_advection_1d": "R grid, models/LinearAdvection1D.jl verbatim: 100 cells, PERIODIC, %d points, 1 var, 3 derivative slots, fp64" % d.n_points,
+                        "rl_cha_bell2024": "RL two-layer shallow-water slab, models/cha_bell2024/Oneway_ShallowWater_Slab.jl verbatim: 100 cells -> 300 native "
                                            "ragged rings (4 + 4 ri points, kmax = ri), %d points x 6 vars, 5 derivative slots, fp64" % d.n_points,
                         "rz_513x128_semi": "RZ %d x %d (radius x Chebyshev levels, b_zDim = zDim), 5 vars, LinearAcousticRZ + semi-implicit adjustment "
                                            "(src/semiimplicit.jl:521-597), fp64" % (d.rDim, d.zDim)}[name],
-           "steps_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "steps": steps, "nan": bool(tile.check_nan()),
+           "steps_per_s": 1.0 / dt, "ms_per_step": 1e3 * dt, "steps": steps, "nan": bool(tile.check_nan()), "graph_replay": graph,
            "survey_bytes_per_step": b_step, "survey_model_frac_of_hbm_peak": b_step / dt / 1e9 / HBM_PEAK_GBS,
            "kernel_ms_per_step_sum": sum(per_step.values()),
            "roofline": ({"bound": "hbm", "kernel": dom, "achieved": rows[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -8,6 +8,13 @@ BCL6 = {"h": "R1T1", "u": "R1T0", "v": "R1T0", "ub": "R1T0", "vb": "R1T0", "wb":
 BCR6 = {"h": "R0", "u": "R1T1", "v": "R0", "ub": "R1T1", "vb": "R0", "wb": "R0"}
 
 
+def config1_r(num_cells=100):
+    """configs[0]: models/LinearAdvection1D.jl (R grid, 100 cells on [-50, 50], PERIODIC, ts 0.05) with the notebook's initial condition."""
+    return dict(name="config1", grid=dict(geometry="R", xmin=-50.0, xmax=50.0, num_cells=num_cells, vars={"u": 1},
+                                          BCL={"u": "PERIODIC"}, BCR={"u": "PERIODIC"}),
+                eq="LinearAdvection1D", ts=0.05, par=dict(c_0=1.0, K=0.0), ic=lambda p: np.exp(-(p[:, 0] / 20.0) ** 2)[:, None])
+
+
 def config2_literal(twoway=False):
     """configs[1]: models/cha_bell2024/Oneway_ShallowWater_Slab.jl verbatim (100 cells, native ragged rings,
     N = 181,800) with the notebook's Rankine vortex + wave-2 perturbation (Cha_Bell_WCD2024_initialization.ipynb)."""

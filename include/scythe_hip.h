@@ -204,6 +204,13 @@ int sx_tile_transform(sx_handle *h);
  * node-space form: after sx_advance the contents of `physical` are unspecified - call sx_tile_transform (the output path,
  * src/semiimplicit.jl:289-290) before sx_get_physical. */
 int sx_advance(sx_handle *h, int32_t t);
+/* model_loop's body for a ONE-tile patch (src/semiimplicit.jl:268-285 with a single worker): advanceTimestep followed by
+ * splineTransform!, i.e. sx_advance(h, t) + sx_spline_transform(h) in one call.  With SX_GRAPH=1 in the environment at sx_create the
+ * step's kernel launches are captured into a hipGraph - once per rotation of the tendency-history buffers, from the third step
+ * this handle executes (Adams-Bashforth-3: the launch arguments then repeat with period 3) - and replayed: ONE graph launch per
+ * step instead of 5-9 kernel launches, for grids whose step is shorter than the host takes to enqueue it (R, RZ and small RL
+ * grids).  Bit-identical to the plain launches; timers on, or a failed capture, fall back to them. */
+int sx_step(sx_handle *h, int32_t t);
 /* physical_model only (src/semiimplicit.jl:357-363) on the current tile.physical */
 int sx_physics(sx_handle *h, int32_t t);
 /* checkCFL (src/semiimplicit.jl:737-751): flag = 1 if any NaN in the model state (scans var_np1, which every

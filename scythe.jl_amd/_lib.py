@@ -71,6 +71,7 @@ SYMBOLS = {
     "sx_spline_transform": (C.c_int, [_H]),
     "sx_tile_transform": (C.c_int, [_H]),
     "sx_advance": (C.c_int, [_H, C.c_int32]),
+    "sx_step": (C.c_int, [_H, C.c_int32]),
     "sx_physics": (C.c_int, [_H, C.c_int32]),
     "sx_check_nan": (C.c_int, [_H, P_I32]),
     "sx_max_abs": (C.c_int, [_H, P_D]),

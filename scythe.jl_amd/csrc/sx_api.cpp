@@ -271,6 +271,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->sbw_mfma = !(getenv("SX_SBW_MFMA") && atoi(getenv("SX_SBW_MFMA")) == 0);
     h->rz_fused = !(getenv("SX_RZ_FUSED") && atoi(getenv("SX_RZ_FUSED")) == 0);
     h->semi_mfma = !(getenv("SX_SEMI_MFMA") && atoi(getenv("SX_SEMI_MFMA")) == 0);
+    h->use_graph = getenv("SX_GRAPH") && atoi(getenv("SX_GRAPH")) != 0;
     h->fft_reg = !(getenv("SX_FFT_REG") && atoi(getenv("SX_FFT_REG")) == 0);
     h->rl_quarter = !(getenv("SX_DFT_RLQ") && atoi(getenv("SX_DFT_RLQ")) == 0);
     h->solve_pcr = getenv("SX_SOLVE_PCR") ? atoi(getenv("SX_SOLVE_PCR")) : -1;
@@ -649,6 +650,8 @@ int sx_destroy(sx_handle *h) {
     sbw_phases_dump();
     dft_phases_dump();
 #endif
+    graphs_release(h);
+    if (h->graph_stream) hipStreamDestroy(h->graph_stream);
     comm_release(h);
     iface_release(h);
     pcr_release(h);
@@ -711,6 +714,7 @@ int sx_get_dims(const sx_handle *h, sx_dims *o) {
 int sx_set_stream(sx_handle *h, void *s) {
     clear_error();
     if (!h) { set_error("null handle"); return 1; }
+    if (h->stream != (hipStream_t)s) graphs_release(h);      // captured on the old stream
     h->stream = (hipStream_t)s;
     return 0;
 }
@@ -996,6 +1000,80 @@ int sx_advance(sx_handle *h, int32_t t) {
     launch_fl_forward(h);
     launch_sb(h);
     h->v_cnt = h->V;
+    return status();
+}
+
+}  // extern "C"
+
+namespace sx {
+void graphs_release(sx_handle *h) {
+    for (auto &g : h->graph_exec) {
+        if (g) hipGraphExecDestroy(g);
+        g = nullptr;
+    }
+}
+
+static void step_launches(sx_handle *h, int t) {          // = sx_advance + sx_spline_transform
+    launch_zinv(h, false);
+    launch_inverse_and_physics(h, t);
+    if (h->defer_diag) { h->v_cnt = h->V - 1; h->diag_dirty = true; }
+    launch_fl_forward(h);
+    launch_sb(h);
+    launch_solve(h);
+    h->v_cnt = h->V;
+}
+}  // namespace sx
+
+extern "C" {
+
+int sx_step(sx_handle *h, int32_t t) {
+    clear_error();
+    if (!h) { set_error("null handle"); return 1; }
+    if (t < 1) { set_error("t is 1-based"); return 1; }
+    if (h->ncells != h->nc) { set_error("sx_step: one-tile patches only (tiles exchange between sx_advance and the solve)"); return 1; }
+    // the first two steps a handle executes are always plain launches: Euler / AB2 arguments, and everything created lazily on a
+    // first launch (work lists, elimination tables, function attributes) must exist before a capture, which may not allocate
+    const bool graph = h->use_graph && !h->timers_on && t >= 3 && h->plain_steps >= 2 && h->eq != SX_EQ_NONE && !h->comm_state;
+    if (!graph) {
+        step_launches(h, t);
+        h->plain_steps++;
+        return status();
+    }
+    const int key = h->rot % 3;
+    if (!h->graph_exec[key]) {
+        // capture this rotation's launches.  The null stream cannot be captured: a handle that runs on it captures and replays on
+        // a private BLOCKING stream, which the null stream's legacy semantics order against everything else the handle does
+        hipStream_t user = h->stream;
+        if (!user && !h->graph_stream && hipStreamCreate(&h->graph_stream) != hipSuccess) { h->use_graph = 0; step_launches(h, t); return status(); }
+        hipStream_t cs = user ? user : h->graph_stream;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ex = nullptr;
+        const int rot0 = h->rot;
+        bool ok = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            h->stream = cs;
+            step_launches(h, t);
+            h->stream = user;
+            ok = hipStreamEndCapture(cs, &g) == hipSuccess && g && !error_status();
+            if (ok) ok = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) == hipSuccess;
+            if (g) hipGraphDestroy(g);
+        }
+        if (!ok) {          // no graphs on this handle from here on; redo the step with plain launches (nothing ran during the capture)
+            (void)hipGetLastError();
+            clear_error();
+            h->use_graph = 0;
+            h->rot = rot0;
+            step_launches(h, t);
+            return status();
+        }
+        h->graph_exec[key] = ex;
+        h->rot = rot0;      // the capture advanced the host-side bookkeeping; the replay below does it again
+    }
+    hipStream_t ls = h->stream ? h->stream : h->graph_stream;
+    HIPOK(hipGraphLaunch(h->graph_exec[key], ls));
+    // what the launchers would have updated on the host
+    h->rot = (h->rot + 2) % 3;
+    if (h->defer_diag) h->diag_dirty = true;
     return status();
 }
 

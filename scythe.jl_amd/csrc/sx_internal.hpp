@@ -153,6 +153,10 @@ struct sx_handle {
     int n_dft_items[3] = {0, 0, 0};
     int n_dft_big[3] = {0, 0, 0};            // of which (listed first) rings with kmax > DFT_KMAX_SINGLE: chunked kernels
     int dft_lcap_small = 0, dft_kcap_small = 0;   // largest ring length / kmax among the other rings
+    // hipGraph replay of a one-tile step (sx_step; SX_GRAPH=1): one instantiated graph per history rotation
+    int use_graph = 0, plain_steps = 0;
+    hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};
+    hipStream_t graph_stream = nullptr;      // capture / replay stream when the handle runs on the (uncapturable) null stream
     int fft_reg = 1;                         // 256-point inverse transforms: register-resident passes with lane swaps (SX_FFT_REG=0: every pass through LDS)
     int rl_quarter = 1;                      // RL grids: quarter-wave DFT kernels over one work list (SX_DFT_RLQ=0: the half-ring kernels in two ring classes)
     int *d_rlq_items[2] = {nullptr, nullptr};    // (ring, part) items of the RL inverse / forward launch, most expensive first
@@ -255,6 +259,7 @@ void clear_error();
 int error_status();   // 1 if set_error has been called since the last clear_error
 void comm_release(sx_handle *h);
 void flush_diag(sx_handle *h);
+void graphs_release(sx_handle *h);
 void iface_release(sx_handle *h);
 void pcr_release(sx_handle *h);
 bool rz_fused(const sx_handle *h);

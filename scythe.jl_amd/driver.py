@@ -411,6 +411,10 @@ class ModelRun:
     def step(self):
         """One pass of model_loop's body (src/semiimplicit.jl:268-297) without the output branch."""
         self.t += 1
+        if self.num_tiles == 1 and self.exchange is None:
+            self._check_stream()
+            self.tiles[0].step(self.t)          # sx_step = sx_advance + sx_spline_transform (one hipGraph launch with SX_GRAPH=1)
+            return
         for g in self.tiles:
             g.advance(self.t)
         self._exchange_and_solve()

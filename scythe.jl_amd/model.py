@@ -327,6 +327,10 @@ class Grid:
     def advance(self, t):
         L.check(self._lib.sx_advance(self._h, int(t)))
 
+    def step(self, t):
+        """One-tile patch: advanceTimestep + splineTransform! in one call (sx_step; replayed from a hipGraph with SX_GRAPH=1)."""
+        L.check(self._lib.sx_step(self._h, int(t)))
+
     def physics(self, t):
         L.check(self._lib.sx_physics(self._h, int(t)))
 

@@ -374,6 +374,60 @@ def test_rl_quarter_wave_dft_kernels_equal_the_half_ring_kernels(monkeypatch, nu
     g0.close()
 
 
+@pytest.mark.parametrize("maker,kw,env", [(cases.kat_r, {}, {}), (cases.r_bcs, {"bcl": "R1T0", "bcr": "R1T1"}, {}), (cases.rz_semiimplicit, {"num_cells": 9, "zDim": 16}, {}),
+                                           (cases.rz_advection, {}, {}), (cases.rl_slab, {"num_cells": 12}, {}), (cases.rl_slab, {"num_cells": 8, "ring_L": 64}, {}),
+                                           (cases.rlz_hrbl, {"num_cells": 6, "zDim": 10}, {}), (cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}, {}),
+                                           (cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}, {"SX_OVERLAP": "1"}),
+                                           (cases.rlz_hrbl, {"num_cells": 8, "zDim": 32, "ring_L": 32}, {"SX_DEFER_DIAG": "1"})])
+def test_step_replayed_from_a_hip_graph_is_bit_identical(monkeypatch, maker, kw, env):
+    """sx_step with SX_GRAPH=1: from the third step on the launches of a step are captured once per rotation of the tendency
+    history and replayed as one hipGraph launch.  Same kernels, same arguments: the fields after 14 steps (Euler, AB2, the three
+    captures, then replays of each) are bit-identical to plain launches - also with the second stream of SX_OVERLAP=1 inside the
+    capture and with the deferred diagnostic variable, whose coefficients must still follow on demand."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    case = maker(**kw)
+    plain = cases.HipModel(case)
+    monkeypatch.setenv("SX_GRAPH", "1")
+    graph = cases.HipModel(case)
+    for _ in range(14):
+        plain.step()
+        graph.step()
+    fa, fb = plain.run.tiles[0].var_np1, graph.run.tiles[0].var_np1
+    assert np.isfinite(fa).all()
+    assert np.array_equal(fa, fb)
+    assert np.array_equal(plain.run.tiles[0].patchSpectral, graph.run.tiles[0].patchSpectral)
+    assert np.array_equal(plain.physical(), graph.physical())
+    # and it keeps stepping correctly after something else used the handle
+    for _ in range(4):
+        plain.step()
+        graph.step()
+    assert np.array_equal(plain.run.tiles[0].var_np1, graph.run.tiles[0].var_np1)
+
+
+def test_step_graph_on_a_user_stream_and_restart(monkeypatch, tmp_path):
+    """The capture on a non-default stream (the caller's torch stream), and a run restarted from a checkpoint at t >= 3: its first two
+    steps are plain launches (lazily created state must exist before a capture), then it captures - bit-identical to the plain run."""
+    import torch
+    case = cases.rlz_hrbl(num_cells=8, zDim=32, ring_L=32)
+    plain = cases.HipModel(case)
+    for _ in range(9):
+        plain.step()
+    ck = str(tmp_path / "ck.npz")
+    plain.run.save_checkpoint(ck)
+    for _ in range(9):
+        plain.step()
+    monkeypatch.setenv("SX_GRAPH", "1")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g = cases.HipModel(case)
+        g.run.load_checkpoint(ck)
+        for _ in range(9):
+            g.step()
+        st.synchronize()
+        assert np.array_equal(plain.run.tiles[0].var_np1, g.run.tiles[0].var_np1)
+
+
 def test_interface_only_solve_refuses_tiles_that_are_too_small():
     import scythe_jl_amd as S
     case = cases.rl_slab(num_cells=9)
