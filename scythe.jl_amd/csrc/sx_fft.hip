@@ -282,8 +282,8 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
     constexpr int FZC = FftCfg<LOGL, HL>::FZC, FNP = FftCfg<LOGL, HL>::FNP, LOGZ = FftCfg<LOGL, HL>::LOGZ;
     // REG: the transform's LDS region only serves the copy-out; ring point l sits at l + (l >> 4), so that the 16 lanes of a row -
     // points 4 a + 16 b after the last register pass - fall into 16 different 16-byte bank groups (stride = 2 mod 16 for the readers)
-    constexpr int SKEW = REG ? 18 : FftCfg<LOGL, HL>::SKEW;
-    static_assert(!REG || (LOGL == 8 && HL == 0 && COPYOUT && !FUSE), "register-resident passes: 256-point transforms with copy-out");
+    constexpr int SKEW = REG ? L / 16 + 2 : FftCfg<LOGL, HL>::SKEW;
+    static_assert(!REG || ((LOGL == 8 || LOGL == 9) && HL == 0 && COPYOUT && !FUSE), "register-resident passes: 256- and 512-point transforms with copy-out");
     extern __shared__ double2 smf[];
     FFT_STAMP(0);
     int nslot = 0;
@@ -428,7 +428,12 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                         // registers of a two-workgroups-per-CU kernel they cost a spilled address, and every reload of it drained the
                         // memory counter - i.e. waited for the previous slot's copy-out stores
                         double2 *wl = smf + SETS * FNP * (L + SKEW);
-                        wl[tt] = twg[tt]; wl[64 + tt] = twg[4 * (tt & 15)]; wl[128 + tt] = twg[16 * (tt & 3)];
+                        constexpr int S2 = L / 256;                     // the 256-point passes' angles in a table of L entries
+                        wl[tt] = twg[S2 * tt]; wl[64 + tt] = twg[S2 * 4 * (tt & 15)]; wl[128 + tt] = twg[S2 * 16 * (tt & 3)];
+                        if (LOGL == 9) {                                // the radix-2 pass in front: e^{+2 pi i (t + 64 q) / 512}
+#pragma unroll
+                            for (int q = 0; q < 4; q++) wl[192 + 64 * q + tt] = twg[tt + 64 * q];
+                        }
                     } else tw.template init<+1>(twg, tt);
                     if (!NODE) {
 #pragma unroll
@@ -459,10 +464,10 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
             par ^= 1;
             if (COPYOUT && SETS == 1 && nslot > 0) lds_barrier();     // the previous slot's copy-out has read this (only) set
             if constexpr (REG) {
-                // packed spectrum W = Za + i Zb of this lane's wavenumbers k = t, t + 64 and of their mirrors L - k
-                double2 wk[2], mir[2];
+                // packed spectrum W = Za + i Zb of this lane's wavenumbers k = t + 64 q (q < NK) and of their mirrors L - k
+                double2 wk[NK], mir[NK];
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
+                for (int q = 0; q < NK; q++) {
                     const int k = kq[q];
                     double2 c = aq[q], e = bq[q];
                     if (ld == 1) { c = make_double2(-k * aq[q].y, k * aq[q].x); e = make_double2(-k * bq[q].y, k * bq[q].x); }
@@ -470,19 +475,44 @@ k_rl_inverse_fft(const AT *__restrict__ Az, Planes<ST> phys, const double *__res
                     wk[q] = make_double2(c.x - e.y, c.y + e.x);
                     mir[q] = k > 0 ? make_double2(c.x + e.y, e.x - c.y) : make_double2(0.0, 0.0);      // k = 0: the Nyquist bin, zero
                 }
-                // x[t + 128] = W[L - (128 - t)] and x[t + 192] = W[L - (64 - t)] are the mirrors lane 64 - t holds (its second / first
-                // wavenumber); lane 0 keeps its own: x[128] = 0 (Nyquist), x[192] = W[L - 64]
+                // the upper half of the input, x[t + 64 q] for q >= NK, are mirrors W[L - k] that lane 64 - t holds: its wavenumber
+                // q' feeds q = 2 NK - 1 - q'; lane 0 keeps its own: x[L / 2] = 0 (Nyquist), x[64 (2 NK - q')] = W[L - 64 q']
                 const int src = (64 - t) & 63;
-                const double2 r0 = fft_bpermute(mir[0], src), r1 = fft_bpermute(mir[1], src);
-                double2 v[4] = {wk[0], wk[1], t == 0 ? r0 : r1, t == 0 ? r1 : r0};
+                double2 r[NK];
+#pragma unroll
+                for (int q = 0; q < NK; q++) r[q] = fft_bpermute(mir[q], src);
                 const double2 *wl = smf + SETS * FNP * (L + SKEW);
                 const double2 wreg[3] = {wl[t], wl[64 + t], wl[128 + t]};
-                fft_reg256_inverse(v, wreg, t);
-                if (nslot == 0) FFT_STAMP(2); else if (nslot == 1) FFT_STAMP(5);
                 const int lb = (t >> 4) + 4 * ((t >> 2) & 3) + 16 * (t & 3);
-                if (active) {
+                if constexpr (LOGL == 8) {
+                    double2 v[4] = {wk[0], wk[1], t == 0 ? r[0] : r[1], t == 0 ? r[1] : r[0]};
+                    fft_reg256_inverse(v, wreg, t);
+                    if (nslot == 0) FFT_STAMP(2); else if (nslot == 1) FFT_STAMP(5);
+                    if (active) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) { const int l = lb + 64 * q; X[l + (l >> 4)] = v[q]; }
+                        for (int q = 0; q < 4; q++) { const int l = lb + 64 * q; X[l + (l >> 4)] = v[q]; }
+                    }
+                } else {
+                    // 512 points: one radix-2 pass in registers (x[m] +- x[m + 256], the difference turned by e^{+2 pi i m / 512}),
+                    // then the even and the odd output points are two independent 256-point transforms
+                    const double2 hi[4] = {t == 0 ? r[0] : r[3], t == 0 ? r[3] : r[2], t == 0 ? r[2] : r[1], t == 0 ? r[1] : r[0]};
+                    double2 ev[4], od[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        ev[q] = cadd(wk[q], hi[q]);
+                        od[q] = cmul(csub(wk[q], hi[q]), wl[192 + 64 * q + t]);
+                    }
+                    fft_reg256_inverse(ev, wreg, t);
+                    fft_reg256_inverse(od, wreg, t);
+                    if (nslot == 0) FFT_STAMP(2); else if (nslot == 1) FFT_STAMP(5);
+                    if (active) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int l = 2 * (lb + 64 * q);
+                            X[l + (l >> 4)] = ev[q];
+                            X[l + 1 + ((l + 1) >> 4)] = od[q];
+                        }
+                    }
                 }
             } else
             if (active) {
@@ -666,7 +696,7 @@ bool fft_fused_zinv(const sx_handle *h) {
 }
 
 static int fft_fzc(int) { return 16; }
-static size_t fft_lds(int L, int sets = 1, bool reg = false) { return sizeof(double2) * ((size_t)sets * (fft_fzc(L) / 2) * (L + (reg ? 18 : L <= 256 ? 2 : 0)) + (reg ? 192 : 0)); }
+static size_t fft_lds(int L, int sets = 1, bool reg = false) { return sizeof(double2) * ((size_t)sets * (fft_fzc(L) / 2) * (L + (reg ? L / 16 + 2 : L <= 256 ? 2 : 0)) + (reg ? (L == 512 ? 448 : 192) : 0)); }
 static int fft_threads(int L, int hl = 0) { return std::max(64, (fft_fzc(L) / 2) * (std::min(L / 4, 64) >> hl)); }       // FNP transforms x LPT lanes
 
 struct InvTarget {          // where an inverse ring launch writes and which unit tables it uses
@@ -709,7 +739,7 @@ static void launch_inv(sx_handle *h, const int *d_mask, const InvTarget &tg, con
     } while (0)
 #define INV_LAUNCH(NODE, ST, AT)                                                                                                     \
     do {                                                                                                                             \
-        if constexpr (LOGL == 8) { if (h->fft_reg) { INV_LAUNCH_REG(NODE, ST, AT); break; } }                                        \
+        if constexpr (LOGL == 8 || LOGL == 9) { if (h->fft_reg) { INV_LAUNCH_REG(NODE, ST, AT); break; } }                                        \
         INV_LAUNCH_V(NODE, ST, AT, 0, 2);                                                                                            \
     } while (0)
 #define INV_LAUNCH_FUSED(ST)                                                                                                         \
