@@ -251,6 +251,240 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
 }
 
 
+// ------------------------------------------------------------------------------------------------ inverse, merged passes (round 4)
+// The kernel above stages ONE coefficient set at a time - value (serving u, d/dlambda, d2/dlambda2: 6 MFMAs per fetched twiddle),
+// then d/dr, d2/dr2, d/dz each alone (2 MFMAs per twiddle) - with a barrier round per set, and spreads a ring's row tiles over its 8
+// waves by whole tiles: 17 tiles take 3 rounds for 2.1 rounds of work.  Here
+//   * a PASS holds up to two sets in LDS (when two fit beside the twiddle table: kmax <= ~270) and up to four planes in the
+//     accumulators: h, ug, vg (u, d/dlambda, d/dr) in ONE pass of 6 MFMAs per twiddle; ub, vb (u, d/dlambda, d2/dlambda2, d/dz | d/dr,
+//     d2/dr2) in two passes of 8 and 4 - half the staging rounds, no 2-MFMA pass left;
+//   * the plane set of a unit of work is a TEMPLATE parameter (MA: which of plain / i k / -k^2 of set A, HASB: set B's plane), so the
+//     inner loop carries no plane bookkeeping (a generic two-set loop was tried in round 2 and lost to exactly that);
+//   * the tiles of the last, partial round are split by PLANES over the idle waves (different planes of one row tile need no
+//     reduction): 17 tiles = 2 rounds + a quarter round instead of 3.
+// SX_DFT_MERGE=0 (read at sx_create) keeps the kernel above.
+struct DftUnitOut { int slot[4]; };      // output slots of the unit's planes: A plain, A ik, A -k^2, B (-1: not in this unit)
+
+template <int MA, bool HASB, class ST>
+__device__ __forceinline__ void dft_unit(const double2 *__restrict__ twl, const double *__restrict__ CcA, const double *__restrict__ CsA,
+                                         const double *__restrict__ CcB, const double *__restrict__ CsB, Planes<ST> phys, int V, int v, int64_t N,
+                                         int64_t p0, int nz, int z0, int zc, int L, int km, int K4, int mt, int lane, const DftUnitOut &o) {
+    const int i = lane & 15, kk = lane >> 4;
+    const int Lh = L / 2, Lq = L / 4;
+    const int lrow = min(mt * 16 + i, Lq);
+    constexpr int NP = ((MA & 1) ? 1 : 0) + ((MA & 2) ? 1 : 0) + ((MA & 4) ? 1 : 0) + (HASB ? 1 : 0);
+    // accumulator index of each plane (compile-time: a running counter inside the loop put the arrays into scratch memory)
+    constexpr int I1 = 0, I2 = (MA & 1) ? 1 : 0, I4 = I2 + ((MA & 2) ? 1 : 0), IB = I4 + ((MA & 4) ? 1 : 0);
+    dft_d4 P[NP][2], Q[NP][2];
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+        for (int par = 0; par < 2; par++) { P[p][par] = dft_d4{0.0, 0.0, 0.0, 0.0}; Q[p][par] = P[p][par]; }
+#pragma unroll
+    for (int par = 0; par < 2; par++) {
+        if (km < par) continue;
+        const int nk = (km - par) / 2 + 1;                  // wavenumbers of this parity
+        int m = (int)(((int64_t)(2 * kk + par) * lrow) % L);
+        const int sm8 = (int)(((int64_t)8 * lrow) % L);
+        double kd = (double)(2 * kk + par);
+        for (int js = 0; js * 4 < nk; js++) {
+            const int k = 8 * js + 2 * kk + par;                     // < K4 (the caller's Kz): rows km + 1 .. Kz - 1 hold zeros
+            const double2 t0 = twl[m];
+            if (MA != 0) {
+                const double bc = CcA[k * CST + i], bs = CsA[k * CST + i];
+                if (MA & 1) {
+                    P[I1][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, P[I1][par], 0, 0, 0);
+                    Q[I1][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, Q[I1][par], 0, 0, 0);
+                }
+                if (MA & 2) {                               // i k (cr + i ci): cosine part -k ci, sine part k cr
+                    P[I2][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, -kd * bs, P[I2][par], 0, 0, 0);
+                    Q[I2][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, kd * bc, Q[I2][par], 0, 0, 0);
+                }
+                if (MA & 4) {
+                    const double k2 = -(kd * kd);
+                    P[I4][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, k2 * bc, P[I4][par], 0, 0, 0);
+                    Q[I4][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, k2 * bs, Q[I4][par], 0, 0, 0);
+                }
+            }
+            if (HASB) {
+                const double bc = CcB[k * CST + i], bs = CsB[k * CST + i];
+                P[IB][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, P[IB][par], 0, 0, 0);
+                Q[IB][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, Q[IB][par], 0, 0, 0);
+            }
+            kd += 8.0;
+            m += sm8;
+            if (m >= L) m -= L;
+        }
+    }
+    if (i >= zc) return;
+    auto put = [&](int slot, int64_t pt, double val) {
+        if (slot == 0) phys.val[(int64_t)v * N + pt] = val;
+        else phys.der[((int64_t)(slot - 1) * V + v) * N + pt] = (ST)val;
+    };
+    int slots[NP];
+    if (MA & 1) slots[I1] = o.slot[0];
+    if (MA & 2) slots[I2] = o.slot[1];
+    if (MA & 4) slots[I4] = o.slot[2];
+    if (HASB) slots[IB] = o.slot[3];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int lo = mt * 16 + kk + 4 * r;
+        if (lo > Lq) continue;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const double Ps = P[p][0][r] + P[p][1][r], Pd = P[p][0][r] - P[p][1][r], Qs = Q[p][0][r] + Q[p][1][r], Qd = Q[p][0][r] - Q[p][1][r];
+            put(slots[p], (p0 + lo) * nz + z0 + i, Ps - Qs);
+            if (lo > 0) put(slots[p], (p0 + (L - lo)) * nz + z0 + i, Ps + Qs);
+            if (lo < Lq) {
+                put(slots[p], (p0 + (Lh - lo)) * nz + z0 + i, Pd + Qd);
+                if (lo > 0) put(slots[p], (p0 + (Lh + lo)) * nz + z0 + i, Pd - Qd);
+            }
+        }
+    }
+}
+
+template <class ST>
+__global__ void __launch_bounds__(512)
+k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi, const int *__restrict__ Lr,
+                        const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
+                        const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
+                        int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow, int s_u, int s_r, int s_rr, int s_l, int s_ll,
+                        int s_z, int s_zz, const int *__restrict__ slotmask, const int *__restrict__ items, int lcap, int kcap4, int two_sets) {
+    extern __shared__ double sm[];
+    const int ring = items[2 * blockIdx.y], v = items[2 * blockIdx.y + 1], z0 = blockIdx.x * DZC;
+    const int mask = slotmask[v];
+    const int zc = min(DZC, nz - z0);
+    const int L = Lr[ring], km = kmaxr[ring];
+    // a K step of parity p touches wavenumbers 8 js + 2 kk + p, js < ceil(nk_p / 4): rows 0 .. Kz - 1 are staged (zeros beyond km), so the
+    // loops carry neither a clamp nor a select
+    const int K4 = 8 * ((km / 2 + 1 + 3) / 4);
+    double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]
+    double *Cset[2][2];                                         // [set A / B][cosine / sine] coefficient tiles [K4][CST]
+    Cset[0][0] = sm + 2 * (size_t)lcap;
+    Cset[0][1] = Cset[0][0] + (size_t)kcap4 * CST;
+    Cset[1][0] = Cset[0][1] + (size_t)kcap4 * CST;
+    Cset[1][1] = Cset[1][0] + (size_t)kcap4 * CST;
+    const int j0 = ring / MUBAR;
+    const double2 *phr = ph + phoff[ring];
+    const int64_t p0 = pstart[ring];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+    for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
+
+    // stored sets q: (sz, d) = (0,0) value [planes u, d/dlambda, d2/dlambda2], (0,1) d/dr, (0,2) d2/dr2, (1,0) d/dz, (2,0) d2/dz2.
+    // Everything about the passes lives in scalars (bit fields), not in indexed private arrays (those would sit in scratch memory).
+    auto has = [&](int sl) { return sl >= 0 && ((mask >> sl) & 1); };
+    const int ma_u = (has(s_u) ? 1 : 0) | (has(s_l) ? 2 : 0) | (has(s_ll) ? 4 : 0);
+    // bit q of `need`: set q is needed; singles = sets 1 .. 4
+    int need = (ma_u ? 1 : 0) | (has(s_r) ? 2 : 0) | (has(s_rr) ? 4 : 0) | ((nsz > 1 && has(s_z)) ? 8 : 0) | ((nsz > 2 && has(s_zz)) ? 16 : 0);
+    auto slot_of = [&](int q) { return q == 1 ? s_r : q == 2 ? s_rr : q == 3 ? s_z : s_zz; };
+    // Staging of a set (as in k_rl_inverse_dft): thread -> (level zz, wavenumber kq + 32 b), the 4 radial rows as 16-byte (Re, Im)
+    // pairs, KB wavenumbers per thread and batch.  (No request-ahead across passes here: its 64 registers are the fourth plane's.)
+    constexpr int KB = 4;
+    const int zz = tid >> 5, kq = tid & 31;
+    const bool zin = zz < zc;
+    auto stage = [&](int q, double *Cc, double *Cs) __attribute__((always_inline)) {
+        const int sz = q < 3 ? 0 : q - 2, d = q < 3 ? q : 0;
+        const double *a = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + (zin ? zz : 0))) * K2;
+        const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
+        const double f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
+        for (int k0 = 0; k0 < K4; k0 += 32 * KB) {
+            double2 raw[KB][4];
+#pragma unroll
+            for (int b = 0; b < KB; b++) {
+                const int kc = min(k0 + kq + 32 * b, km);
+#pragma unroll
+                for (int r = 0; r < 4; r++) raw[b][r] = *reinterpret_cast<const double2 *>(a + r * azrow + 2 * kc);
+            }
+#pragma unroll
+            for (int b = 0; b < KB; b++) {
+                const int k = k0 + kq + 32 * b;
+                if (k >= K4 || zz >= DZC) continue;
+                double cr = 0.0, ci = 0.0;
+                if (zin && k <= km) {
+                    cr = f0 * raw[b][0].x + f1 * raw[b][1].x + f2 * raw[b][2].x + f3 * raw[b][3].x;
+                    if (k > 0) {
+                        ci = f0 * raw[b][0].y + f1 * raw[b][1].y + f2 * raw[b][2].y + f3 * raw[b][3].y;
+                        const double2 w = phr[k];               // e^{+i k off}
+                        const double tr = cr * w.x - ci * w.y;
+                        ci = 2.0 * (cr * w.y + ci * w.x);
+                        cr = 2.0 * tr;
+                    }
+                }
+                Cc[k * CST + zz] = cr;
+                Cs[k * CST + zz] = ci;
+            }
+        }
+    };
+    const int T = L / 4 / 16 + 1;                               // row tiles of the quarter ring
+    const int F = T - T % nw, R = T - F;                        // whole rounds of tiles, tiles of the last (partial) round
+
+    // passes: the lowest remaining set as A and - if two sets fit the LDS - the HIGHEST remaining single-plane set as B
+    while (need) {
+        const int qa = __ffs(need) - 1;
+        need &= ~(1 << qa);
+        int qb = -1;
+        if (two_sets && (need & ~1)) {
+            qb = 31 - __clz(need & ~1);
+            need &= ~(1 << qb);
+        }
+        __syncthreads();                                        // the previous pass has been consumed (and twl is complete)
+        stage(qa, Cset[0][0], Cset[0][1]);
+        if (qb >= 0) stage(qb, Cset[1][0], Cset[1][1]);
+        __syncthreads();
+        const int maf = qa == 0 ? ma_u : 1;
+        const bool hb = qb >= 0;
+        DftUnitOut of;
+        of.slot[0] = qa == 0 ? s_u : slot_of(qa); of.slot[1] = s_l; of.slot[2] = s_ll; of.slot[3] = hb ? slot_of(qb) : -1;
+        // one unit = (row tile, plane subset): dispatch to the instance whose plane set is compiled in
+        auto run = [&](int mt, int ma, bool b) {
+#define DFT_U(MA_, B_) dft_unit<MA_, B_, ST>(twl, Cset[0][0], Cset[0][1], Cset[1][0], Cset[1][1], phys, V, v, N, p0, nz, z0, zc, L, km, K4, mt, lane, of)
+            switch ((ma << 1) | (b ? 1 : 0)) {
+                case 1: DFT_U(0, true); break;
+                case 2: DFT_U(1, false); break;
+                case 3: DFT_U(1, true); break;
+                case 4: DFT_U(2, false); break;
+                case 5: DFT_U(2, true); break;
+                case 6: DFT_U(3, false); break;
+                case 7: DFT_U(3, true); break;
+                case 8: DFT_U(4, false); break;
+                case 9: DFT_U(4, true); break;
+                case 10: DFT_U(5, false); break;
+                case 11: DFT_U(5, true); break;
+                case 12: DFT_U(6, false); break;
+                case 13: DFT_U(6, true); break;
+                case 14: DFT_U(7, false); break;
+                case 15: DFT_U(7, true); break;
+                default: break;
+            }
+#undef DFT_U
+        };
+        // this wave's units: one whole tile per full round, then (last, partial round of R tiles) one plane group of one tile: the
+        // planes of those tiles are split into g groups over the waves (wave -> tile wave / g, group wave % g).  ONE call site, so
+        // that the dispatcher is inlined once.
+        const int nfull = F / nw;
+        for (int u = 0; u <= nfull; u++) {
+            int mt = wave + u * nw, ma = maf;
+            bool b = hb;
+            if (u == nfull) {
+                if (R == 0) break;
+                const int npl = __popc(maf) + (hb ? 1 : 0);
+                const int g = min(npl, nw / R);
+                const int r = wave / g, grp = wave % g;
+                if (r >= R) break;
+                // planes in the order A plain, A ik, A -k^2, B; group grp takes planes [grp * npl / g, (grp + 1) * npl / g)
+                const int lo = grp * npl / g, hi = (grp + 1) * npl / g;
+                int idx = 0;
+                ma = 0; b = false;
+                for (int bit = 1; bit <= 4; bit <<= 1)
+                    if (maf & bit) { if (idx >= lo && idx < hi) ma |= bit; idx++; }
+                if (hb && idx >= lo && idx < hi) b = true;
+                mt = F + r;
+            }
+            run(mt, ma, b);
+        }
+    }
+}
+
 // The same transform for rings whose coefficient sets do not fit the LDS next to the twiddle table (kmax > 319, i.e. native
 // patches of more than 106 cells: a 171-cell patch has rings of 2,052 points with kmax 512).  Loop order inverted: a
 // workgroup owns ONE group of 8 row tiles (128 points of the quarter ring, blockIdx.z), its accumulators stay in registers
@@ -1064,6 +1298,26 @@ void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
         const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)2 * kcap4 * CST);
         dim3 g((h->nz + DZC - 1) / DZC, h->n_dft_items[which] - nbig, 1);
         if (g.y == 0) { timer_end(h); return; }
+        if (h->dft_merge) {
+            const int kz = 8 * ((h->dft_kcap_small / 2 + 1 + 3) / 4);          // rows a K step can touch (see the kernel)
+            const size_t lds2 = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * kz * CST);
+            const int two = lds2 <= 160 * 1024 ? 1 : 0;            // two coefficient sets beside the twiddle table: kmax <= ~260
+            const size_t ldsm = two ? lds2 : sizeof(double) * (2 * (size_t)lcap + (size_t)2 * kz * CST);
+#define DFT_INVM(ST)                                                                                                                 \
+            {                                                                                                                        \
+                auto kern = k_rl_inverse_dft_merged<ST>;                                                                             \
+                HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm)); \
+                hipLaunchKernelGGL(kern, g, dim3(512), ldsm, h->stream, az, planes_of<ST>(h->d_phys, h->V, h->N), h->d_phi, h->d_L,  \
+                                   h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2,     \
+                                   h->nrings, h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5],   \
+                                   h->slot[6], d_mask, h->d_dft_items[which] + 2 * nbig, lcap, kz, two);                             \
+            }
+            if (h->f32) DFT_INVM(float) else DFT_INVM(double)
+#undef DFT_INVM
+            HIPCHK3(hipGetLastError());
+            timer_end(h);
+            return;
+        }
 #define DFT_INV(ST)                                                                                                                  \
         {                                                                                                                            \
             auto kern = k_rl_inverse_dft<ST>;                                                                                        \

@@ -428,6 +428,44 @@ def test_step_graph_on_a_user_stream_and_restart(monkeypatch, tmp_path):
         assert np.array_equal(plain.run.tiles[0].var_np1, g.run.tiles[0].var_np1)
 
 
+@pytest.mark.parametrize("num_cells,zDim", [(6, 10), (23, 16), (44, 20), (67, 16), (86, 8), (100, 8)])
+def test_merged_pass_native_inverse_dft_equals_the_one_set_per_pass_kernel(monkeypatch, num_cells, zDim):
+    """RLZ grids on native ragged rings: the merged-pass inverse DFT kernel (round 4, the default: two coefficient sets and up to
+    four planes per pass, plane sets compiled into the loop, the last round's row tiles split by planes over the idle waves)
+    against the one-set-per-pass kernel (SX_DFT_MERGE=0): every derivative slot of tileTransform! (the full slot mask) on random
+    coefficients, and the fields after 3 steps of the boundary-layer set (the equation set's slot masks: 3 planes for h, ug, vg,
+    6 for ub, vb) - ring counts with every remainder of row tiles modulo the 8 waves, and patches too large for two sets in LDS."""
+    import scythe_jl_amd as S
+    case = cases.rlz_hrbl(num_cells=num_cells, zDim=zDim)
+    case["ts"] = 0.2
+    gp, mp = cases.hip_params(case)
+    g1 = S.Grid(gp, mp)
+    monkeypatch.setenv("SX_DFT_MERGE", "0")
+    g0 = S.Grid(gp, mp)
+    monkeypatch.delenv("SX_DFT_MERGE")
+    rng = np.random.default_rng(17)
+    a = rng.standard_normal((int(g1.dims.s_patch), g1.V))
+    out = []
+    for g in (g1, g0):
+        g.set_patch_spectral_a(a)
+        g.tileTransform_()
+        out.append(g.physical)
+    for d in range(out[0].shape[2]):
+        assert cases.rel_err(out[0][:, :, d], out[1][:, :, d]) < 1e-12, d
+    g1.close()
+    g0.close()
+    m1 = cases.HipModel(case)
+    monkeypatch.setenv("SX_DFT_MERGE", "0")
+    m0 = cases.HipModel(case)
+    for _ in range(3):
+        m1.step()
+        m0.step()
+    f1, f0 = m1.run.tiles[0].var_np1, m0.run.tiles[0].var_np1
+    assert np.isfinite(f1).all()
+    for v in range(f1.shape[1]):
+        assert np.abs(f1[:, v] - f0[:, v]).max() <= 1e-11 * max(np.abs(f0[:, v]).max(), 1e-300), v
+
+
 def test_interface_only_solve_refuses_tiles_that_are_too_small():
     import scythe_jl_amd as S
     case = cases.rl_slab(num_cells=9)
