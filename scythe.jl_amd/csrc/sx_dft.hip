@@ -378,8 +378,9 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
     int need = (ma_u ? 1 : 0) | (has(s_r) ? 2 : 0) | (has(s_rr) ? 4 : 0) | ((nsz > 1 && has(s_z)) ? 8 : 0) | ((nsz > 2 && has(s_zz)) ? 16 : 0);
     auto slot_of = [&](int q) { return q == 1 ? s_r : q == 2 ? s_rr : q == 3 ? s_z : s_zz; };
     // Staging of a set (as in k_rl_inverse_dft): thread -> (level zz, wavenumber kq + 32 b), the 4 radial rows as 16-byte (Re, Im)
-    // pairs, KB wavenumbers per thread and batch.  (No request-ahead across passes here: its 64 registers are the fourth plane's.)
-    constexpr int KB = 4;
+    // pairs, KB wavenumbers per thread and batch: 256 wavenumbers of a set - every ring of a <= 85-cell patch whole - are requested in ONE
+    // burst (128 registers that are free while no accumulator lives).  (No request-ahead across passes here: its registers are the fourth plane's.)
+    constexpr int KB = 4;      // (8 - a whole 256-wavenumber set in one burst - measured slower: 0.984 vs 0.956 ms)
     const int zz = tid >> 5, kq = tid & 31;
     const bool zin = zz < zc;
     auto stage = [&](int q, double *Cc, double *Cs) __attribute__((always_inline)) {
@@ -417,6 +418,8 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
     };
     const int T = L / 4 / 16 + 1;                               // row tiles of the quarter ring
     const int F = T - T % nw, R = T - F;                        // whole rounds of tiles, tiles of the last (partial) round
+    [[maybe_unused]] const long long dbg_t0 = DFT_NOW();
+    [[maybe_unused]] long long dbg_stage = 0, dbg_mm = 0, dbg_units = 0, dbg_wait = 0;
 
     // passes: the lowest remaining set as A and - if two sets fit the LDS - the HIGHEST remaining single-plane set as B
     while (need) {
@@ -427,10 +430,15 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
             qb = 31 - __clz(need & ~1);
             need &= ~(1 << qb);
         }
+        [[maybe_unused]] const long long dbg_t1 = DFT_NOW();
         __syncthreads();                                        // the previous pass has been consumed (and twl is complete)
+        [[maybe_unused]] const long long dbg_t1b = DFT_NOW();
+        dbg_wait += dbg_t1b - dbg_t1;
         stage(qa, Cset[0][0], Cset[0][1]);
         if (qb >= 0) stage(qb, Cset[1][0], Cset[1][1]);
         __syncthreads();
+        [[maybe_unused]] const long long dbg_t2 = DFT_NOW();
+        dbg_stage += dbg_t2 - dbg_t1b;
         const int maf = qa == 0 ? ma_u : 1;
         const bool hb = qb >= 0;
         DftUnitOut of;
@@ -481,8 +489,16 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
                 mt = F + r;
             }
             run(mt, ma, b);
+            dbg_units++;
         }
+        dbg_mm += DFT_NOW() - dbg_t2;
     }
+#ifdef SX_PHASES
+    if (tid == 0 && g_dft_dbg) {       // [0] total, [1] staging, [2] units (loops + stores) of wave 0, [3] wait at the pass barrier, [4] units of wave 0, [5] L
+        long long *o = g_dft_dbg + (((int64_t)ring * V + v) * gridDim.x + blockIdx.x) * 8;
+        o[0] = DFT_NOW() - dbg_t0; o[1] = dbg_stage; o[2] = dbg_mm; o[3] = dbg_wait; o[4] = dbg_units; o[5] = L; o[6] = 0; o[7] = 0;
+    }
+#endif
 }
 
 // The same transform for rings whose coefficient sets do not fit the LDS next to the twiddle table (kmax > 319, i.e. native
