@@ -100,6 +100,13 @@ FLAGS = {"SX_OVERLAP": ["0", "1", "2"], "SX_DEFER_DIAG": ["0", "1"], "SX_FUSE_ZI
          "SX_WIDE": ["1", "0"], "SX_SBW_MFMA": ["1", "0"], "SX_SBW_PF": ["1", "0"]}
 
 
+# round-4 kernels and the kernels they replace (per-handle switches read at sx_create): parallel-cyclic-reduction / serial spline solve,
+# fused matrix-core / general RZ transforms, matrix-core / scalar semi-implicit adjustment, register / LDS passes of the inverse FFT,
+# merged-pass / one-set-per-pass native inverse DFT, quarter-wave / half-ring RL DFT kernels, hipGraph replay / plain launches
+FLAGS_R4 = {"SX_SOLVE_PCR": ["0", "1"], "SX_RZ_FUSED": ["0", "1"], "SX_SEMI_MFMA": ["0", "1"], "SX_FFT_REG": ["0", "1"], "SX_DFT_MERGE": ["0", "1"],
+            "SX_DFT_RLQ": ["0", "1"], "SX_GRAPH": ["0", "1"]}
+
+
 def draw_fast(rng):
     """The shapes the tuned kernels serve (uniform power-of-two rings, 32 / 64 levels, the boundary-layer set) with random
     per-handle switches (read at sx_create): second stream, deferred diagnostic variable, fused vertical inverse, ring-wise
@@ -192,6 +199,10 @@ def test_seeded_random_configurations_against_the_oracle():
             case, tiles, exchange, impl, flags = draw_fast(rng)
         else:
             case, tiles, exchange, impl = draw(rng, medium)
+            if os.environ.get("SCYTHE_FUZZ_SWITCHES", "r4") == "r4":       # every other draw runs with some of the round-4 switches flipped
+                sw = np.random.default_rng(1000003 * i + 17)              # (its own generator: the drawn configurations stay those of round 3)
+                if sw.random() < 0.5:
+                    flags = {k: str(sw.choice(v)) for k, v in FLAGS_R4.items() if sw.random() < 0.5}
         what = describe(case, tiles, exchange, impl) + (" " + " ".join("%s=%s" % kv for kv in sorted(flags.items())) if flags else "")
         saved = {k: os.environ.get(k) for k in flags}
         os.environ.update(flags)
