@@ -240,7 +240,7 @@ def load_pmc(S, workload):
     return pmc
 
 
-def time_other_config(S, torch, dev, name, steps, warmup, graph=None):
+def time_other_config(S, torch, dev, name, steps, warmup, graph_replay=True):
     """BASELINE.json config 2 / 3 on this GPU: `warmup` steps with an event pair around every kernel (the per-kernel table), then
     `steps` timed steps with no event on the stream (ms_per_step).  Returns the dictionary reported under other_configs."""
     import bench_configs as BC
@@ -270,6 +270,8 @@ def time_other_config(S, torch, dev, name, steps, warmup, graph=None):
     # the same steps replayed from hipGraphs (sx_step with SX_GRAPH=1: one graph launch per step; bit-identical fields)
     graph = None
     try:
+        if not graph_replay:
+            raise RuntimeError("skipped (--no-graph-replay)")
         os.environ["SX_GRAPH"] = "1"
         rung = S.ModelRun(mp, num_tiles=1, device=dev)
         os.environ.pop("SX_GRAPH", None)
@@ -337,6 +339,7 @@ def main():
     ap.add_argument("--no-selfcheck", action="store_true", help="N > 1: skip the 2-step comparison of the two exchange implementations")
     ap.add_argument("--no-native", action="store_true", help="skip the native-ragged-ring run reported as native_equivalent")
     ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE.json configs 2 and 3 (other_configs)")
+    ap.add_argument("--no-graph-replay", action="store_true", help="other configs: skip the second run that replays the steps from hipGraphs")
     ap.add_argument("--no-kernel-timers", action="store_true", help="diagnostic: no hipEvent pair per kernel anywhere (no roofline object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=0, help="0 = time the C port on the full grid (default); n > 0 = extrapolate from n cells")
@@ -366,7 +369,7 @@ def main():
         # configs 2 / 3 as the line's own workload (one GPU): value = that configuration's steps/s, labelled as not the headline
         if world != 1:
             raise SystemExit("bench.py: --workload %s is a one-GPU configuration" % args.workload)
-        r = time_other_config(S, torch, dev, args.workload, args.steps, max(args.warmup, 1))
+        r = time_other_config(S, torch, dev, args.workload, args.steps, max(args.warmup, 1), graph_replay=not args.no_graph_replay)
         out = {"metric": "model steps/sec, %s (BASELINE.json config, not the headline configuration)" % args.workload,
                "value": None if r["nan"] else r["steps_per_s"], "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd /tmp
 for pair in "config2 rl_cha_bell2024" "config3 rz_513x128_semi"; do
   set -- $pair
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$1 -o $1 -- python3 $ROOT/bench.py --workload $2 --steps 200 --warmup 20 ${EXTRA_BENCH_ARGS} > $OUT/$1_bench_under_rocprof.json 2> $OUT/stats_$1.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$1 -o $1 -- python3 $ROOT/bench.py --workload $2 --steps 200 --warmup 20 --no-graph-replay ${EXTRA_BENCH_ARGS} > $OUT/$1_bench_under_rocprof.json 2> $OUT/stats_$1.log
   cp $(find $OUT/stats_$1 -name "*kernel_stats.csv" | head -1) $OUT/$1_kernel_stats.csv
   head -12 $OUT/$1_kernel_stats.csv
 done
