@@ -343,13 +343,197 @@ __device__ __forceinline__ void dft_unit(const double2 *__restrict__ twl, const 
     }
 }
 
-template <class ST>
+// Eighth-wave form of a unit (round 4).  With M = L / 4 the EVEN wavenumbers of the quarter ring are a series of period 2 M sampled on
+// half a period, so they fold once more about M / 2:  cos(k theta (M - l)) = +cos(k theta l) for k = 0 mod 4, -cos for k = 2 mod 4, and
+// sin(k theta (M - l)) = -sin / +sin.  (The odd wavenumbers do not fold: their cosine becomes a sine.)  A unit therefore owns a row tile
+// l = 16 mt .. of the EIGHTH ring and the mirrored rows M - l:
+//   even k: classes k = 0, 2 mod 4 at rows l only        E0c, E0s, E2c, E2s    (K / 4 wavenumbers each)
+//   odd k : rows l and rows M - l                        Oc, Os, Oc', Os'      (K / 2 wavenumbers each)
+//   rows l    :  Pe = E0c + E2c   Qe = E0s + E2s   Po = Oc    Qo = Os
+//   rows M - l:  Pe = E0c - E2c   Qe = E2s - E0s   Po = Oc'   Qo = Os'          and the four ring points of a row as in the quarter-wave form
+// - 3/4 of the quarter-wave form's matrix-core work (the even half of it halves), for eight accumulator tiles per plane instead of
+// four: a unit carries at most two planes (NPM of the kernel).
+template <int MA, bool HASB, class ST>
+__device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const double *__restrict__ CcA, const double *__restrict__ CsA,
+                                          const double *__restrict__ CcB, const double *__restrict__ CsB, Planes<ST> phys, int V, int v, int64_t N,
+                                          int64_t p0, int nz, int z0, int zc, int L, int km, int mt, int lane, const DftUnitOut &o,
+                                          [[maybe_unused]] long long &dbg_loops) {
+    const int i = lane & 15, kk = lane >> 4;
+    const int Lh = L / 2, M = L / 4, Mh = M / 2;
+    [[maybe_unused]] const long long dbg_l0 = DFT_NOW();
+    const int lrow = min(mt * 16 + i, Mh), lmir = M - lrow;
+    constexpr int NP = ((MA & 1) ? 1 : 0) + ((MA & 2) ? 1 : 0) + ((MA & 4) ? 1 : 0) + (HASB ? 1 : 0);
+    constexpr int I1 = 0, I2 = (MA & 1) ? 1 : 0, I4 = I2 + ((MA & 2) ? 1 : 0), IB = I4 + ((MA & 4) ? 1 : 0);
+    dft_d4 Ec[NP][2], Es[NP][2], Oc[NP][2], Os[NP][2];       // E*[plane][class 0 / 2], O*[plane][rows l / rows M - l]
+#pragma unroll
+    for (int p = 0; p < NP; p++)
+#pragma unroll
+        for (int c = 0; c < 2; c++) { Ec[p][c] = dft_d4{0.0, 0.0, 0.0, 0.0}; Es[p][c] = Ec[p][c]; Oc[p][c] = Ec[p][c]; Os[p][c] = Ec[p][c]; }
+#define DFT8_MM(acc, a, b) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0)
+    // Both loops are software-pipelined by hand, two K steps per iteration with alternating operand sets: the operands of step
+    // js + 1 (two twiddles, the coefficient pairs) are requested from the LDS BEFORE the matrix-core instructions of step js are
+    // issued and waited for BEHIND them (scheduling barriers and an opaque use pin both: the compiler's own loop reads, waits, then
+    // issues; it rotated a plain one-step prefetch back into that form and sank the requests of a conditional second step into the
+    // branch).  The read-wait-issue form ran at 0.905 or 1.47 ms depending on where ONE 4-byte instruction in front of the loops put
+    // them in memory (profiles/r04/eighth_wave_alignment.txt); this form is 0.905-0.912 ms at eight different offsets.  An odd step
+    // count runs one step on zero rows (the staged rows end at a multiple of 32); the last request goes one step beyond them (inside
+    // the LDS allocation: the launcher adds 32 rows; the values are not used).
+    struct OddOps { double2 t, tm; double ac, as, bc, bs; };
+    struct EvenOps { double2 t0, t2; double ac0, as0, ac2, as2, bc0, bs0, bc2, bs2; };
+    if (km >= 1) {                                            // odd wavenumbers k = 8 js + 2 kk + 1, rows l and M - l
+        const int nst = ((km - 1) / 2 + 1 + 3) / 4;
+        int m = ((2 * kk + 1) * lrow) % L, mm = ((2 * kk + 1) * lmir) % L;
+        const int s8 = (8 * lrow) % L, sm8 = (8 * lmir) % L;
+        double kd = (double)(2 * kk + 1);
+        int ko = (2 * kk + 1) * CST + i;                       // rows km + 1 .. Kz - 1 of the coefficient tiles hold zeros
+        auto load = [&](OddOps &x) __attribute__((always_inline)) {
+            x.t = twl[m]; x.tm = twl[mm];
+            if (MA != 0) { x.ac = CcA[ko]; x.as = CsA[ko]; }
+            if (HASB) { x.bc = CcB[ko]; x.bs = CsB[ko]; }
+            m += s8; if (m >= L) m -= L;
+            mm += sm8; if (mm >= L) mm -= L;
+            ko += 8 * CST;
+        };
+        auto hold = [&](OddOps &x) __attribute__((always_inline)) {      // the values exist from here on (an opaque use: the loads cannot move past it)
+            asm volatile("" : "+v"(x.t.x), "+v"(x.t.y), "+v"(x.tm.x), "+v"(x.tm.y));
+            if (MA != 0) asm volatile("" : "+v"(x.ac), "+v"(x.as));
+            if (HASB) asm volatile("" : "+v"(x.bc), "+v"(x.bs));
+        };
+        auto mma = [&](const OddOps &x) __attribute__((always_inline)) {
+            if (MA & 1) {
+                DFT8_MM(Oc[I1][0], x.t.x, x.ac); DFT8_MM(Os[I1][0], x.t.y, x.as); DFT8_MM(Oc[I1][1], x.tm.x, x.ac); DFT8_MM(Os[I1][1], x.tm.y, x.as);
+            }
+            if (MA & 2) {                                      // i k (cr + i ci): cosine part -k ci, sine part k cr
+                const double b1 = -kd * x.as, b2 = kd * x.ac;
+                DFT8_MM(Oc[I2][0], x.t.x, b1); DFT8_MM(Os[I2][0], x.t.y, b2); DFT8_MM(Oc[I2][1], x.tm.x, b1); DFT8_MM(Os[I2][1], x.tm.y, b2);
+            }
+            if (MA & 4) {
+                const double k2 = -(kd * kd), b1 = k2 * x.ac, b2 = k2 * x.as;
+                DFT8_MM(Oc[I4][0], x.t.x, b1); DFT8_MM(Os[I4][0], x.t.y, b2); DFT8_MM(Oc[I4][1], x.tm.x, b1); DFT8_MM(Os[I4][1], x.tm.y, b2);
+            }
+            if (HASB) {
+                DFT8_MM(Oc[IB][0], x.t.x, x.bc); DFT8_MM(Os[IB][0], x.t.y, x.bs); DFT8_MM(Oc[IB][1], x.tm.x, x.bc); DFT8_MM(Os[IB][1], x.tm.y, x.bs);
+            }
+            kd += 8.0;
+        };
+        OddOps A{}, B{};
+        load(A);
+        hold(A);
+        for (int js = 0; js < nst; js += 2) {
+            load(B);
+            __builtin_amdgcn_sched_barrier(0);                 // the requests stay in front of the matrix-core instructions ...
+            mma(A);
+            __builtin_amdgcn_sched_barrier(0);
+            hold(B);                                           // ... and are waited for behind them
+            load(A);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(B);                                            // (an odd count's extra step multiplies zero rows)
+            __builtin_amdgcn_sched_barrier(0);
+            hold(A);
+        }
+    }
+    {                                                         // even wavenumbers: k = 16 js + 4 kk (class 0) and + 2 (class 2), rows l
+        const int nst = (km / 4 + 1 + 3) / 4;
+        int m0 = (4 * kk * lrow) % L, m2 = ((4 * kk + 2) * lrow) % L;
+        const int s16 = (16 * lrow) % L;
+        double kd0 = (double)(4 * kk), kd2 = kd0 + 2.0;
+        int ko = 4 * kk * CST + i;
+        auto load = [&](EvenOps &x) __attribute__((always_inline)) {
+            x.t0 = twl[m0]; x.t2 = twl[m2];
+            if (MA != 0) { x.ac0 = CcA[ko]; x.as0 = CsA[ko]; x.ac2 = CcA[ko + 2 * CST]; x.as2 = CsA[ko + 2 * CST]; }
+            if (HASB) { x.bc0 = CcB[ko]; x.bs0 = CsB[ko]; x.bc2 = CcB[ko + 2 * CST]; x.bs2 = CsB[ko + 2 * CST]; }
+            m0 += s16; if (m0 >= L) m0 -= L;
+            m2 += s16; if (m2 >= L) m2 -= L;
+            ko += 16 * CST;
+        };
+        auto hold = [&](EvenOps &x) __attribute__((always_inline)) {
+            asm volatile("" : "+v"(x.t0.x), "+v"(x.t0.y), "+v"(x.t2.x), "+v"(x.t2.y));
+            if (MA != 0) asm volatile("" : "+v"(x.ac0), "+v"(x.as0), "+v"(x.ac2), "+v"(x.as2));
+            if (HASB) asm volatile("" : "+v"(x.bc0), "+v"(x.bs0), "+v"(x.bc2), "+v"(x.bs2));
+        };
+        auto mma = [&](const EvenOps &x) __attribute__((always_inline)) {
+            if (MA & 1) {
+                DFT8_MM(Ec[I1][0], x.t0.x, x.ac0); DFT8_MM(Es[I1][0], x.t0.y, x.as0); DFT8_MM(Ec[I1][1], x.t2.x, x.ac2); DFT8_MM(Es[I1][1], x.t2.y, x.as2);
+            }
+            if (MA & 2) {
+                DFT8_MM(Ec[I2][0], x.t0.x, -kd0 * x.as0); DFT8_MM(Es[I2][0], x.t0.y, kd0 * x.ac0);
+                DFT8_MM(Ec[I2][1], x.t2.x, -kd2 * x.as2); DFT8_MM(Es[I2][1], x.t2.y, kd2 * x.ac2);
+            }
+            if (MA & 4) {
+                const double q0 = -(kd0 * kd0), q2 = -(kd2 * kd2);
+                DFT8_MM(Ec[I4][0], x.t0.x, q0 * x.ac0); DFT8_MM(Es[I4][0], x.t0.y, q0 * x.as0);
+                DFT8_MM(Ec[I4][1], x.t2.x, q2 * x.ac2); DFT8_MM(Es[I4][1], x.t2.y, q2 * x.as2);
+            }
+            if (HASB) {
+                DFT8_MM(Ec[IB][0], x.t0.x, x.bc0); DFT8_MM(Es[IB][0], x.t0.y, x.bs0); DFT8_MM(Ec[IB][1], x.t2.x, x.bc2); DFT8_MM(Es[IB][1], x.t2.y, x.bs2);
+            }
+            kd0 += 16.0; kd2 += 16.0;
+        };
+        EvenOps A{}, B{};
+        load(A);
+        hold(A);
+        for (int js = 0; js < nst; js += 2) {
+            load(B);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(A);
+            __builtin_amdgcn_sched_barrier(0);
+            hold(B);
+            load(A);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(B);
+            __builtin_amdgcn_sched_barrier(0);
+            hold(A);
+        }
+    }
+#undef DFT8_MM
+#ifdef SX_PHASES
+    asm volatile("s_nop 0" : "+v"(Ec[0][0]), "+v"(Es[0][1]), "+v"(Oc[0][0]), "+v"(Os[0][1]));      // the accumulators are final here
+#endif
+    dbg_loops += DFT_NOW() - dbg_l0;
+    if (i >= zc) return;
+    auto put = [&](int slot, int64_t pt, double val) {
+        if (slot == 0) phys.val[(int64_t)v * N + pt] = val;
+        else phys.der[((int64_t)(slot - 1) * V + v) * N + pt] = (ST)val;
+    };
+    auto put4 = [&](int slot, int lo, double Pe, double Po, double Qe, double Qo) {
+        const double Ps = Pe + Po, Pd = Pe - Po, Qs = Qe + Qo, Qd = Qe - Qo;
+        put(slot, (p0 + lo) * nz + z0 + i, Ps - Qs);
+        if (lo > 0) put(slot, (p0 + (L - lo)) * nz + z0 + i, Ps + Qs);
+        if (lo < M) {
+            put(slot, (p0 + (Lh - lo)) * nz + z0 + i, Pd + Qd);
+            if (lo > 0) put(slot, (p0 + (Lh + lo)) * nz + z0 + i, Pd - Qd);
+        }
+    };
+    int slots[NP];
+    if (MA & 1) slots[I1] = o.slot[0];
+    if (MA & 2) slots[I2] = o.slot[1];
+    if (MA & 4) slots[I4] = o.slot[2];
+    if (HASB) slots[IB] = o.slot[3];
+    // (the caller runs the plane chunks of a tile in a loop: an opaque copy of the tile index keeps the compiler from hoisting the 32
+    // point offsets of the stores out of that loop - it spilled them, and a spill reload waits for every store in flight.  An
+    // unguarded form of these stores for tiles without an end row, 32-bit offsets from per-plane bases, was measured: 0.915 vs 0.907 ms.)
+    int mto = mt;
+    asm volatile("" : "+v"(mto));
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int lo = mto * 16 + kk + 4 * r;
+        if (lo > Mh) continue;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            put4(slots[p], lo, Ec[p][0][r] + Ec[p][1][r], Oc[p][0][r], Es[p][0][r] + Es[p][1][r], Os[p][0][r]);
+            if (M - lo != lo) put4(slots[p], M - lo, Ec[p][0][r] - Ec[p][1][r], Oc[p][1][r], Es[p][1][r] - Es[p][0][r], Os[p][1][r]);
+        }
+    }
+}
+
+template <class ST, int NPM>      // NPM = 0: quarter-wave units, any plane set; 2: eighth-wave units of at most NPM planes
 __global__ void __launch_bounds__(512)
 k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi, const int *__restrict__ Lr,
                         const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
                         const double2 *__restrict__ tw, const int64_t *__restrict__ phoff, const double2 *__restrict__ ph, int V,
                         int nz, int nsz, int K2, int nrings, int64_t N, int64_t azrow, int s_u, int s_r, int s_rr, int s_l, int s_ll,
                         int s_z, int s_zz, const int *__restrict__ slotmask, const int *__restrict__ items, int lcap, int kcap4, int two_sets) {
+    constexpr bool E8 = NPM > 0;
     extern __shared__ double sm[];
     const int ring = items[2 * blockIdx.y], v = items[2 * blockIdx.y + 1], z0 = blockIdx.x * DZC;
     const int mask = slotmask[v];
@@ -357,7 +541,8 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
     const int L = Lr[ring], km = kmaxr[ring];
     // a K step of parity p touches wavenumbers 8 js + 2 kk + p, js < ceil(nk_p / 4): rows 0 .. Kz - 1 are staged (zeros beyond km), so the
     // loops carry neither a clamp nor a select
-    const int K4 = 8 * ((km / 2 + 1 + 3) / 4);
+    // (eighth-wave units: classes k = 0 / 2 mod 4 advance by 16 per K step, two steps per loop iteration: rows up to the next multiple of 32)
+    const int K4 = E8 ? 32 * ((km + 1 + 31) / 32) : 8 * ((km / 2 + 1 + 3) / 4);
     double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]
     double *Cset[2][2];                                         // [set A / B][cosine / sine] coefficient tiles [K4][CST]
     Cset[0][0] = sm + 2 * (size_t)lcap;
@@ -416,10 +601,13 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
             }
         }
     };
-    const int T = L / 4 / 16 + 1;                               // row tiles of the quarter ring
+    const int T = E8 ? L / 8 / 16 + 1 : L / 4 / 16 + 1;         // row tiles of the quarter ring (E8: of the eighth ring, each with its mirrored rows)
     const int F = T - T % nw, R = T - F;                        // whole rounds of tiles, tiles of the last (partial) round
     [[maybe_unused]] const long long dbg_t0 = DFT_NOW();
-    [[maybe_unused]] long long dbg_stage = 0, dbg_mm = 0, dbg_units = 0, dbg_wait = 0;
+    [[maybe_unused]] long long dbg_stage = 0, dbg_mm = 0, dbg_units = 0, dbg_wait = 0, dbg_loops = 0;
+#ifdef SX_PHASES
+    const long long dbg_r0 = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 
     // passes: the lowest remaining set as A and - if two sets fit the LDS - the HIGHEST remaining single-plane set as B
     while (need) {
@@ -445,7 +633,14 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
         of.slot[0] = qa == 0 ? s_u : slot_of(qa); of.slot[1] = s_l; of.slot[2] = s_ll; of.slot[3] = hb ? slot_of(qb) : -1;
         // one unit = (row tile, plane subset): dispatch to the instance whose plane set is compiled in
         auto run = [&](int mt, int ma, bool b) {
-#define DFT_U(MA_, B_) dft_unit<MA_, B_, ST>(twl, Cset[0][0], Cset[0][1], Cset[1][0], Cset[1][1], phys, V, v, N, p0, nz, z0, zc, L, km, K4, mt, lane, of)
+#define DFT_U(MA_, B_)                                                                                                                 \
+    do {                                                                                                                               \
+        constexpr int np_ = ((MA_) & 1) + (((MA_) >> 1) & 1) + (((MA_) >> 2) & 1) + ((B_) ? 1 : 0);                                    \
+        if constexpr (E8 && np_ <= NPM)                                                                                                \
+            dft_unit8<MA_, B_, ST>(twl, Cset[0][0], Cset[0][1], Cset[1][0], Cset[1][1], phys, V, v, N, p0, nz, z0, zc, L, km, mt, lane, of, dbg_loops);   \
+        else if constexpr (!E8)                                                                                                        \
+            dft_unit<MA_, B_, ST>(twl, Cset[0][0], Cset[0][1], Cset[1][0], Cset[1][1], phys, V, v, N, p0, nz, z0, zc, L, km, K4, mt, lane, of);   \
+    } while (0)
             switch ((ma << 1) | (b ? 1 : 0)) {
                 case 1: DFT_U(0, true); break;
                 case 2: DFT_U(1, false); break;
@@ -488,7 +683,20 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
                 if (hb && idx >= lo && idx < hi) b = true;
                 mt = F + r;
             }
-            run(mt, ma, b);
+            // eighth-wave units hold 8 accumulator tiles per plane: at most NPM planes per call; still ONE call site per instantiation
+            if constexpr (!E8) {
+                run(mt, ma, b);
+            } else {
+                do {
+                    int cma = 0, cnt = 0;
+                    bool cb = false;
+                    for (int bit = 1; bit <= 4; bit <<= 1)
+                        if ((ma & bit) && cnt < NPM) { cma |= bit; cnt++; }
+                    ma &= ~cma;
+                    if (b && cnt < NPM) { cb = true; b = false; }
+                    run(mt, cma, cb);
+                } while (ma || b);
+            }
             dbg_units++;
         }
         dbg_mm += DFT_NOW() - dbg_t2;
@@ -496,7 +704,8 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
 #ifdef SX_PHASES
     if (tid == 0 && g_dft_dbg) {       // [0] total, [1] staging, [2] units (loops + stores) of wave 0, [3] wait at the pass barrier, [4] units of wave 0, [5] L
         long long *o = g_dft_dbg + (((int64_t)ring * V + v) * gridDim.x + blockIdx.x) * 8;
-        o[0] = DFT_NOW() - dbg_t0; o[1] = dbg_stage; o[2] = dbg_mm; o[3] = dbg_wait; o[4] = dbg_units; o[5] = L; o[6] = 0; o[7] = 0;
+        o[0] = DFT_NOW() - dbg_t0; o[1] = dbg_stage; o[2] = dbg_mm; o[3] = dbg_wait; o[4] = dbg_units + (dbg_loops << 8); o[5] = L;          // units in the low byte, cycles inside the matrix-core loops of the eighth-wave units above
+        o[6] = (long long)__builtin_amdgcn_s_memrealtime() - dbg_r0; o[7] = dbg_r0;      // 100 MHz ticks: duration, start
     }
 #endif
 }
@@ -1315,13 +1524,15 @@ void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
         dim3 g((h->nz + DZC - 1) / DZC, h->n_dft_items[which] - nbig, 1);
         if (g.y == 0) { timer_end(h); return; }
         if (h->dft_merge) {
-            const int kz = 8 * ((h->dft_kcap_small / 2 + 1 + 3) / 4);          // rows a K step can touch (see the kernel)
-            const size_t lds2 = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * kz * CST);
+            const bool e8 = h->dft_eighth != 0;
+            const int kz = e8 ? 32 * ((h->dft_kcap_small + 1 + 31) / 32) : 8 * ((h->dft_kcap_small / 2 + 1 + 3) / 4);          // rows a K step can touch (see the kernel)
+            const size_t pad = e8 ? sizeof(double) * 32 * CST : 0;     // the pipelined loops request one K step beyond the staged rows
+            const size_t lds2 = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * kz * CST) + pad;
             const int two = lds2 <= 160 * 1024 ? 1 : 0;            // two coefficient sets beside the twiddle table: kmax <= ~260
-            const size_t ldsm = two ? lds2 : sizeof(double) * (2 * (size_t)lcap + (size_t)2 * kz * CST);
+            const size_t ldsm = two ? lds2 : sizeof(double) * (2 * (size_t)lcap + (size_t)2 * kz * CST) + pad;
 #define DFT_INVM(ST)                                                                                                                 \
             {                                                                                                                        \
-                auto kern = k_rl_inverse_dft_merged<ST>;                                                                             \
+                auto kern = e8 ? k_rl_inverse_dft_merged<ST, 2> : k_rl_inverse_dft_merged<ST, 0>;                                    \
                 HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm)); \
                 hipLaunchKernelGGL(kern, g, dim3(512), ldsm, h->stream, az, planes_of<ST>(h->d_phys, h->V, h->N), h->d_phi, h->d_L,  \
                                    h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2,     \

@@ -466,6 +466,50 @@ def test_merged_pass_native_inverse_dft_equals_the_one_set_per_pass_kernel(monke
         assert np.abs(f1[:, v] - f0[:, v]).max() <= 1e-11 * max(np.abs(f0[:, v]).max(), 1e-300), v
 
 
+@pytest.mark.parametrize("planes", [2, 3])
+@pytest.mark.parametrize("num_cells,zDim", [(3, 8), (4, 8), (6, 10), (23, 16), (44, 20), (67, 16), (86, 8), (100, 8)])
+def test_eighth_wave_native_inverse_dft_equals_the_one_set_per_pass_kernel(monkeypatch, num_cells, zDim, planes):
+    """The eighth-wave units of the merged kernel (even wavenumbers folded once more about a quarter of the quarter ring, rows l and
+    L/4 - l in one unit; SX_DFT_EIGHTH = planes per unit) against the one-set-per-pass quarter-wave kernel: every slot of
+    tileTransform! on random coefficients and 3 steps of the boundary-layer set.  Ring lengths 4 .. 404: L/4 odd and even (with and
+    without a self-mirrored row), one to four eighth-ring row tiles, the last round split by planes."""
+    import scythe_jl_amd as S
+    case = cases.rlz_hrbl(num_cells=num_cells, zDim=zDim)
+    case["ts"] = 0.2
+    gp, mp = cases.hip_params(case)
+    monkeypatch.setenv("SX_DFT_EIGHTH", str(planes))
+    g1 = S.Grid(gp, mp)
+    monkeypatch.delenv("SX_DFT_EIGHTH")
+    monkeypatch.setenv("SX_DFT_MERGE", "0")
+    g0 = S.Grid(gp, mp)
+    monkeypatch.delenv("SX_DFT_MERGE")
+    rng = np.random.default_rng(23)
+    a = rng.standard_normal((int(g1.dims.s_patch), g1.V))
+    out = []
+    for g in (g1, g0):
+        g.set_patch_spectral_a(a)
+        g.tileTransform_()
+        out.append(g.physical)
+    for d in range(out[0].shape[2]):
+        assert cases.rel_err(out[0][:, :, d], out[1][:, :, d]) < 1e-12, d
+    g1.close()
+    g0.close()
+    if num_cells < 3:
+        return
+    monkeypatch.setenv("SX_DFT_EIGHTH", str(planes))
+    m1 = cases.HipModel(case)
+    monkeypatch.delenv("SX_DFT_EIGHTH")
+    monkeypatch.setenv("SX_DFT_MERGE", "0")
+    m0 = cases.HipModel(case)
+    for _ in range(3):
+        m1.step()
+        m0.step()
+    f1, f0 = m1.run.tiles[0].var_np1, m0.run.tiles[0].var_np1
+    assert np.isfinite(f1).all()
+    for v in range(f1.shape[1]):
+        assert np.abs(f1[:, v] - f0[:, v]).max() <= 1e-11 * max(np.abs(f0[:, v]).max(), 1e-300), v
+
+
 def test_interface_only_solve_refuses_tiles_that_are_too_small():
     import scythe_jl_amd as S
     case = cases.rl_slab(num_cells=9)
