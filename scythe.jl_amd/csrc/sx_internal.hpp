@@ -158,7 +158,7 @@ struct sx_handle {
     hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};
     hipStream_t graph_stream = nullptr;      // capture / replay stream when the handle runs on the (uncapturable) null stream
     int fft_reg = 1;                         // 256-point inverse transforms: register-resident passes with lane swaps (SX_FFT_REG=0: every pass through LDS)
-    int dft_eighth = 0;                      // merged kernel in its eighth-wave form (SX_DFT_EIGHTH = planes per unit, 2 or 3; 0: quarter-wave units)
+    int dft_eighth = 2;                      // merged kernel: eighth-wave units of two planes (round 4; SX_DFT_EIGHTH=0: quarter-wave units of up to four)
     int dft_merge = 1;                       // RLZ native rings: merged-pass inverse DFT kernel (SX_DFT_MERGE=0: one set per pass, whole tiles per wave)
     int rl_quarter = 1;                      // RL grids: quarter-wave DFT kernels over one work list (SX_DFT_RLQ=0: the half-ring kernels in two ring classes)
     int *d_rlq_items[2] = {nullptr, nullptr};    // (ring, part) items of the RL inverse / forward launch, most expensive first
