@@ -661,43 +661,40 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
             }
 #undef DFT_U
         };
-        // this wave's units: one whole tile per full round, then (last, partial round of R tiles) one plane group of one tile: the
-        // planes of those tiles are split into g groups over the waves (wave -> tile wave / g, group wave % g).  ONE call site, so
-        // that the dispatcher is inlined once.
+        // This wave's units: one whole tile per full round; the R tiles of the last (partial) round as R x npl (tile, plane) pairs dealt
+        // out in runs of ceil(R npl / 8) consecutive pairs (different planes of a row tile need no reduction; a run may span two tiles).
+        // A unit runs in chunks of at most CH planes.  ONE loop with ONE call site, so that the dispatcher is inlined once.
         const int nfull = F / nw;
-        for (int u = 0; u <= nfull; u++) {
-            int mt = wave + u * nw, ma = maf;
-            bool b = hb;
-            if (u == nfull) {
-                if (R == 0) break;
-                const int npl = __popc(maf) + (hb ? 1 : 0);
-                const int g = min(npl, nw / R);
-                const int r = wave / g, grp = wave % g;
-                if (r >= R) break;
-                // planes in the order A plain, A ik, A -k^2, B; group grp takes planes [grp * npl / g, (grp + 1) * npl / g)
-                const int lo = grp * npl / g, hi = (grp + 1) * npl / g;
-                int idx = 0;
-                ma = 0; b = false;
-                for (int bit = 1; bit <= 4; bit <<= 1)
-                    if (maf & bit) { if (idx >= lo && idx < hi) ma |= bit; idx++; }
-                if (hb && idx >= lo && idx < hi) b = true;
-                mt = F + r;
-            }
-            // eighth-wave units hold 8 accumulator tiles per plane: at most NPM planes per call; still ONE call site per instantiation
-            if constexpr (!E8) {
-                run(mt, ma, b);
-            } else {
-                do {
-                    int cma = 0, cnt = 0;
-                    bool cb = false;
+        const int npl = __popc(maf) + (hb ? 1 : 0);
+        const int cper = (R * npl + nw - 1) / nw;
+        int j = wave * cper;
+        const int j1 = min(j + cper, R * npl);
+        int u = 0, mt = 0, ma = 0;
+        bool b = false;
+        constexpr int CH = E8 ? NPM : 4;                        // eighth-wave units hold 8 accumulator tiles per plane
+        for (;;) {
+            if (!ma && !b) {                                    // next unit of this wave
+                if (u < nfull) {
+                    mt = wave + u * nw; ma = maf; b = hb;
+                    u++;
+                } else if (j < j1) {                            // planes in the order A plain, A ik, A -k^2, B
+                    const int tile = j / npl, lo = j - tile * npl, hi = min(npl, lo + (j1 - j));
+                    int idx = 0;
                     for (int bit = 1; bit <= 4; bit <<= 1)
-                        if ((ma & bit) && cnt < NPM) { cma |= bit; cnt++; }
-                    ma &= ~cma;
-                    if (b && cnt < NPM) { cb = true; b = false; }
-                    run(mt, cma, cb);
-                } while (ma || b);
+                        if (maf & bit) { if (idx >= lo && idx < hi) ma |= bit; idx++; }
+                    if (hb && idx >= lo && idx < hi) b = true;
+                    mt = F + tile;
+                    j += hi - lo;
+                } else break;
+                dbg_units++;
             }
-            dbg_units++;
+            int cma = 0, cnt = 0;
+            bool cb = false;
+            for (int bit = 1; bit <= 4; bit <<= 1)
+                if ((ma & bit) && cnt < CH) { cma |= bit; cnt++; }
+            ma &= ~cma;
+            if (b && cnt < CH) { cb = true; b = false; }
+            run(mt, cma, cb);
         }
         dbg_mm += DFT_NOW() - dbg_t2;
     }
