@@ -511,6 +511,33 @@ def test_eighth_wave_native_inverse_dft_equals_the_one_set_per_pass_kernel(monke
         assert np.abs(f1[:, v] - f0[:, v]).max() <= 1e-11 * max(np.abs(f0[:, v]).max(), 1e-300), v
 
 
+@pytest.mark.parametrize("num_cells,zDim", [(23, 16), (67, 16)])
+def test_eighth_wave_units_with_fp32_stored_derivative_planes(monkeypatch, num_cells, zDim):
+    """storage = "f32" on native ragged rings: the eighth-wave units write the derivative planes as fp32 (their float
+    instantiation) - same values as the quarter-wave one-set-per-pass kernel's fp32 planes to rounding of the fp32 store, and
+    within the declared fp32 bars of the all-fp64 planes."""
+    import scythe_jl_amd as S
+    case = cases.rlz_hrbl(num_cells=num_cells, zDim=zDim)
+    gp32, mp32 = cases.hip_params(case, storage="f32")
+    gp64, mp64 = cases.hip_params(case)
+    g8 = S.Grid(gp32, mp32)
+    monkeypatch.setenv("SX_DFT_MERGE", "0")
+    g0 = S.Grid(gp32, mp32)
+    monkeypatch.delenv("SX_DFT_MERGE")
+    g64 = S.Grid(gp64, mp64)
+    rng = np.random.default_rng(29)
+    a = rng.standard_normal((int(g8.dims.s_patch), g8.V))
+    out = []
+    for g in (g8, g0, g64):
+        g.set_patch_spectral_a(a)
+        g.tileTransform_()
+        out.append(g.physical)
+        g.close()
+    for d in range(out[0].shape[2]):
+        assert cases.rel_err(out[0][:, :, d], out[1][:, :, d]) < (1e-12 if d == 0 else 2e-7), d      # value slot fp64, derivative slots one fp32 ulp
+        assert cases.rel_err(out[0][:, :, d], out[2][:, :, d]) < (1e-12 if d == 0 else 5e-7), d
+
+
 def test_interface_only_solve_refuses_tiles_that_are_too_small():
     import scythe_jl_amd as S
     case = cases.rl_slab(num_cells=9)
