@@ -1078,21 +1078,38 @@ k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, cons
     const double *x = np1 + (int64_t)v * N + p0 * nz + z0;
     const double *Fc = F + (size_t)(2 * par) * LCQ * CST, *Fs = Fc + (size_t)LCQ * CST;
 
+    // The four ring points of a (row, level) of chunk c + 1 are requested before the matrix-core steps of chunk c (round 4: 2 x 4
+    // values per thread in registers), folded and written to the LDS after them: a chunk used to start with a full round trip to
+    // HBM in front of its fold.  Clamped addresses, no branches in the request; the end rows l = 0, L/4 pick their two values below.
+    constexpr int NIT = LCQ * DZC / 512;                        // (row, level) items per thread and chunk
+    static_assert(LCQ * DZC % 512 == 0, "items per thread");
+    double xa[NIT], xb[NIT], xc4[NIT], xd[NIT];
+    auto request = [&](int lc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int o = tid + it * 512;
+            const int zz = min(o & (DZC - 1), zc - 1), l = min(lc + (o >> 4), Lq);
+            xa[it] = x[(int64_t)l * nz + zz];
+            xb[it] = x[(int64_t)(l == 0 ? 0 : L - l) * nz + zz];
+            xc4[it] = x[(int64_t)(Lh - l) * nz + zz];
+            xd[it] = x[(int64_t)(Lh + l) * nz + zz];
+        }
+    };
+    request(0);
     for (int lc = 0; lc <= Lq; lc += LCQ) {
         __syncthreads();
-        for (int o = tid; o < LCQ * DZC; o += blockDim.x) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int o = tid + it * 512;
             const int zz = o & (DZC - 1), r = o >> 4, l = lc + r;
             double ce = 0.0, se = 0.0, co = 0.0, so = 0.0;
             if (zz < zc && l <= Lq) {
-                const double a = x[(int64_t)l * nz + zz];
-                if (l == 0) {
-                    const double c = x[(int64_t)Lh * nz + zz];
+                const double a = xa[it], b = xb[it], c = xc4[it], d = xd[it];
+                if (l == 0) {                                   // c = x[L/2]
                     ce = a + c; co = a - c;
-                } else if (l == Lq) {
-                    const double b = x[(int64_t)(L - l) * nz + zz];
+                } else if (l == Lq) {                           // b = x[L - L/4]
                     ce = a + b; so = a - b;
                 } else {
-                    const double b = x[(int64_t)(L - l) * nz + zz], c = x[(int64_t)(Lh - l) * nz + zz], d = x[(int64_t)(Lh + l) * nz + zz];
                     const double ab = a + b, cd = c + d, amb = a - b, dmc = d - c;
                     ce = ab + cd; co = ab - cd; se = amb + dmc; so = amb - dmc;
                 }
@@ -1102,6 +1119,7 @@ k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, cons
             F[(2 * LCQ + r) * CST + zz] = co;
             F[(3 * LCQ + r) * CST + zz] = so;
         }
+        if (lc + LCQ <= Lq) request(lc + LCQ);                  // in flight during this chunk's matrix-core steps
         __syncthreads();
         if (tq * 16 >= nk) continue;                                // nothing for this wave (uniform)
         const int ln4 = (min(LCQ, Lq + 1 - lc) + 3) & ~3;           // rows past Lq are staged as zeros
