@@ -1043,7 +1043,11 @@ k_fl_forward_dft(const double *__restrict__ np1, double *__restrict__ Fl, const 
 // - half the matrix-core work of the half-ring form.  Wave w transforms wavenumbers of parity w & 1 (tiles of 16: k = 2 (16 t
 // + n) + parity, t = (w >> 1) + 4 q), so ONE fetch of the folded values feeds all its tiles (6 MFMAs per fetch with three
 // tiles; the f64 matrix cores sustain 65 TFLOP/s that way against 50 at 2 per fetch, profiles/micro/mfma_f64_rate.hip).
-constexpr int LCQ = 64;       // quarter-ring points per staged chunk
+constexpr int LCQ = 64;       // quarter-ring points per staged chunk (RL grids)
+#ifndef SX_LCZ
+#define SX_LCZ 64
+#endif
+constexpr int LCZ = SX_LCZ;   // the same for k_fl_forward_dft_q (RLZ grids; measured: 64: 0.265 ms, 96: 0.262, 128 - one workgroup per CU by LDS: 0.399)
 
 __global__ void __launch_bounds__(512)
 k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, const int *__restrict__ Lr,
@@ -1055,7 +1059,7 @@ k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, cons
     const int zc = min(DZC, nz - z0);
     const int L = Lr[ring], km = kmaxr[ring], Lh = L / 2, Lq = L / 4;
     double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]
-    double *F = sm + 2 * (size_t)lcap;                          // [parity][cosine / sine part][LCQ][CST]
+    double *F = sm + 2 * (size_t)lcap;                          // [parity][cosine / sine part][LCZ][CST]
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1076,13 +1080,13 @@ k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, cons
         fourk[q] = (int)(((int64_t)4 * kq[q]) % L);
     }
     const double *x = np1 + (int64_t)v * N + p0 * nz + z0;
-    const double *Fc = F + (size_t)(2 * par) * LCQ * CST, *Fs = Fc + (size_t)LCQ * CST;
+    const double *Fc = F + (size_t)(2 * par) * LCZ * CST, *Fs = Fc + (size_t)LCZ * CST;
 
     // The four ring points of a (row, level) of chunk c + 1 are requested before the matrix-core steps of chunk c (round 4: 2 x 4
     // values per thread in registers), folded and written to the LDS after them: a chunk used to start with a full round trip to
     // HBM in front of its fold.  Clamped addresses, no branches in the request; the end rows l = 0, L/4 pick their two values below.
-    constexpr int NIT = LCQ * DZC / 512;                        // (row, level) items per thread and chunk
-    static_assert(LCQ * DZC % 512 == 0, "items per thread");
+    constexpr int NIT = LCZ * DZC / 512;                        // (row, level) items per thread and chunk
+    static_assert(LCZ * DZC % 512 == 0, "items per thread");
     double xa[NIT], xb[NIT], xc4[NIT], xd[NIT];
     auto request = [&](int lc) __attribute__((always_inline)) {
 #pragma unroll
@@ -1096,7 +1100,7 @@ k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, cons
         }
     };
     request(0);
-    for (int lc = 0; lc <= Lq; lc += LCQ) {
+    for (int lc = 0; lc <= Lq; lc += LCZ) {
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
@@ -1114,15 +1118,15 @@ k_fl_forward_dft_q(const double *__restrict__ np1, double *__restrict__ Fl, cons
                     ce = ab + cd; co = ab - cd; se = amb + dmc; so = amb - dmc;
                 }
             }
-            F[(0 * LCQ + r) * CST + zz] = ce;
-            F[(1 * LCQ + r) * CST + zz] = se;
-            F[(2 * LCQ + r) * CST + zz] = co;
-            F[(3 * LCQ + r) * CST + zz] = so;
+            F[(0 * LCZ + r) * CST + zz] = ce;
+            F[(1 * LCZ + r) * CST + zz] = se;
+            F[(2 * LCZ + r) * CST + zz] = co;
+            F[(3 * LCZ + r) * CST + zz] = so;
         }
-        if (lc + LCQ <= Lq) request(lc + LCQ);                  // in flight during this chunk's matrix-core steps
+        if (lc + LCZ <= Lq) request(lc + LCZ);                  // in flight during this chunk's matrix-core steps
         __syncthreads();
         if (tq * 16 >= nk) continue;                                // nothing for this wave (uniform)
-        const int ln4 = (min(LCQ, Lq + 1 - lc) + 3) & ~3;           // rows past Lq are staged as zeros
+        const int ln4 = (min(LCZ, Lq + 1 - lc) + 3) & ~3;           // rows past Lq are staged as zeros
         int m[NTW];
 #pragma unroll
         for (int q = 0; q < NTW; q++) m[q] = (int)(((int64_t)kq[q] * (lc + kk)) % L);
@@ -1601,7 +1605,7 @@ void launch_fl_forward_dft(sx_handle *h) {
             if (n == 0) continue;
             const int lcap = part == 0 ? h->L_max : h->dft_lcap_small;
             const int kparts = part == 0 ? ((h->kmax_max / 2 + 1 + 15) / 16 + 4 * NTW - 1) / (4 * NTW) : 1;
-            const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * LCQ * CST);
+            const size_t lds = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * LCZ * CST);
             dim3 g((h->nz + DZC - 1) / DZC, n, kparts);
             HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fl_forward_dft_q), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(k_fl_forward_dft_q, g, dim3(512), lds, h->stream, h->d_np1, h->d_Fl, h->d_L, h->d_kmax, h->d_pstart,
