@@ -274,6 +274,7 @@ int sx_create(const sx_grid_desc *g, const sx_model_desc *m, sx_handle **out) {
     h->use_graph = getenv("SX_GRAPH") && atoi(getenv("SX_GRAPH")) != 0;
     h->fft_reg = !(getenv("SX_FFT_REG") && atoi(getenv("SX_FFT_REG")) == 0);
     h->dft_merge = !(getenv("SX_DFT_MERGE") && atoi(getenv("SX_DFT_MERGE")) == 0);
+    if (getenv("SX_DFT_HALFWG")) h->dft_half_wg = atoi(getenv("SX_DFT_HALFWG")) != 0;
     if (getenv("SX_DFT_EIGHTH")) h->dft_eighth = atoi(getenv("SX_DFT_EIGHTH")) != 0 ? 2 : 0;
     h->rl_quarter = !(getenv("SX_DFT_RLQ") && atoi(getenv("SX_DFT_RLQ")) == 0);
     h->solve_pcr = getenv("SX_SOLVE_PCR") ? atoi(getenv("SX_SOLVE_PCR")) : -1;

@@ -353,7 +353,7 @@ __device__ __forceinline__ void dft_unit(const double2 *__restrict__ twl, const 
 //   rows M - l:  Pe = E0c - E2c   Qe = E2s - E0s   Po = Oc'   Qo = Os'          and the four ring points of a row as in the quarter-wave form
 // - 3/4 of the quarter-wave form's matrix-core work (the even half of it halves), for eight accumulator tiles per plane instead of
 // four: a unit carries at most two planes (NPM of the kernel).
-template <int MA, bool HASB, class ST>
+template <int MA, bool HASB, class ST, bool HT>      // HT: the twiddle table holds half the ring, tw[m + L/2] = -tw[m]
 __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const double *__restrict__ CcA, const double *__restrict__ CsA,
                                           const double *__restrict__ CcB, const double *__restrict__ CsB, Planes<ST> phys, int V, int v, int64_t N,
                                           int64_t p0, int nz, int z0, int zc, int L, int km, int mt, int lane, const DftUnitOut &o,
@@ -378,6 +378,15 @@ __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const
     // them in memory (profiles/r04/eighth_wave_alignment.txt); this form is 0.905-0.912 ms at eight different offsets.  An odd step
     // count runs one step on zero rows (the staged rows end at a multiple of 32); the last request goes one step beyond them (inside
     // the LDS allocation: the launcher adds 32 rows; the values are not used).
+    auto tw_at = [&](int m) __attribute__((always_inline)) {
+        if constexpr (!HT) return twl[m];
+        else {
+            const bool ng = m >= Lh;
+            double2 t = twl[ng ? m - Lh : m];
+            if (ng) { t.x = -t.x; t.y = -t.y; }
+            return t;
+        }
+    };
     struct OddOps { double2 t, tm; double ac, as, bc, bs; };
     struct EvenOps { double2 t0, t2; double ac0, as0, ac2, as2, bc0, bs0, bc2, bs2; };
     if (km >= 1) {                                            // odd wavenumbers k = 8 js + 2 kk + 1, rows l and M - l
@@ -387,7 +396,7 @@ __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const
         double kd = (double)(2 * kk + 1);
         int ko = (2 * kk + 1) * CST + i;                       // rows km + 1 .. Kz - 1 of the coefficient tiles hold zeros
         auto load = [&](OddOps &x) __attribute__((always_inline)) {
-            x.t = twl[m]; x.tm = twl[mm];
+            x.t = tw_at(m); x.tm = tw_at(mm);
             if (MA != 0) { x.ac = CcA[ko]; x.as = CsA[ko]; }
             if (HASB) { x.bc = CcB[ko]; x.bs = CsB[ko]; }
             m += s8; if (m >= L) m -= L;
@@ -439,7 +448,7 @@ __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const
         double kd0 = (double)(4 * kk), kd2 = kd0 + 2.0;
         int ko = 4 * kk * CST + i;
         auto load = [&](EvenOps &x) __attribute__((always_inline)) {
-            x.t0 = twl[m0]; x.t2 = twl[m2];
+            x.t0 = tw_at(m0); x.t2 = tw_at(m2);
             if (MA != 0) { x.ac0 = CcA[ko]; x.as0 = CsA[ko]; x.ac2 = CcA[ko + 2 * CST]; x.as2 = CsA[ko + 2 * CST]; }
             if (HASB) { x.bc0 = CcB[ko]; x.bs0 = CsB[ko]; x.bc2 = CcB[ko + 2 * CST]; x.bs2 = CsB[ko + 2 * CST]; }
             m0 += s16; if (m0 >= L) m0 -= L;
@@ -526,7 +535,11 @@ __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const
     }
 }
 
-template <class ST, int NPM>      // NPM = 0: quarter-wave units, any plane set; 2: eighth-wave units of at most NPM planes
+// HT (round 4, rings whose ONE coefficient set and HALF twiddle table fit 80 KB of LDS: kmax <= 255): launched with 256 threads, one set per
+// pass, the table behind the set - TWO workgroups per CU, each on its own (ring, variable, level chunk): while one stages a set, drains its
+// stores or waits at a barrier, the other has the matrix pipes to itself.  (One 512-thread workgroup owns a CU's whole LDS; nothing ran
+// under the 45 % of its time that are not matrix-core loops.)
+template <class ST, int NPM, bool HT = false>      // NPM = 0: quarter-wave units, any plane set; 2: eighth-wave units of at most NPM planes
 __global__ void __launch_bounds__(512)
 k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const double *__restrict__ phi, const int *__restrict__ Lr,
                         const int *__restrict__ kmaxr, const int64_t *__restrict__ pstart, const int64_t *__restrict__ twoff,
@@ -543,9 +556,11 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
     // loops carry neither a clamp nor a select
     // (eighth-wave units: classes k = 0 / 2 mod 4 advance by 16 per K step, two steps per loop iteration: rows up to the next multiple of 32)
     const int K4 = E8 ? 32 * ((km + 1 + 31) / 32) : 8 * ((km / 2 + 1 + 3) / 4);
-    double2 *twl = reinterpret_cast<double2 *>(sm);             // [L]
+    // [L] twiddles, then the sets; HT: the ONE set first, then [L / 2] twiddles (the pipelined loops' last request, one step beyond
+    // the set's rows, then lands in the table instead of needing rows of its own)
+    double2 *twl = reinterpret_cast<double2 *>(HT ? sm + (size_t)2 * kcap4 * CST : sm);
     double *Cset[2][2];                                         // [set A / B][cosine / sine] coefficient tiles [K4][CST]
-    Cset[0][0] = sm + 2 * (size_t)lcap;
+    Cset[0][0] = HT ? sm : sm + 2 * (size_t)lcap;
     Cset[0][1] = Cset[0][0] + (size_t)kcap4 * CST;
     Cset[1][0] = Cset[0][1] + (size_t)kcap4 * CST;
     Cset[1][1] = Cset[1][0] + (size_t)kcap4 * CST;
@@ -553,7 +568,7 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    for (int m = tid; m < L; m += blockDim.x) twl[m] = tw[twoff[ring] + m];
+    for (int m = tid; m < (HT ? L / 2 : L); m += blockDim.x) twl[m] = tw[twoff[ring] + m];
 
     // stored sets q: (sz, d) = (0,0) value [planes u, d/dlambda, d2/dlambda2], (0,1) d/dr, (0,2) d2/dr2, (1,0) d/dz, (2,0) d2/dz2.
     // Everything about the passes lives in scalars (bit fields), not in indexed private arrays (those would sit in scratch memory).
@@ -566,24 +581,25 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
     // pairs, KB wavenumbers per thread and batch: 256 wavenumbers of a set - every ring of a <= 85-cell patch whole - are requested in ONE
     // burst (128 registers that are free while no accumulator lives).  (No request-ahead across passes here: its registers are the fourth plane's.)
     constexpr int KB = 4;      // (8 - a whole 256-wavenumber set in one burst - measured slower: 0.984 vs 0.956 ms)
-    const int zz = tid >> 5, kq = tid & 31;
+    const int lgq = HT ? 4 : 5, NQ = 1 << lgq;                   // 512 threads = 16 levels x 32 wavenumbers (HT: 256 = 16 x 16)
+    const int zz = tid >> lgq, kq = tid & (NQ - 1);
     const bool zin = zz < zc;
     auto stage = [&](int q, double *Cc, double *Cs) __attribute__((always_inline)) {
         const int sz = q < 3 ? 0 : q - 2, d = q < 3 ? q : 0;
         const double *a = Az + (int64_t)j0 * azrow + (((int64_t)v * nsz + sz) * nz + (z0 + (zin ? zz : 0))) * K2;
         const double *pf = phi + ((int64_t)d * nrings + ring) * 4;
         const double f0 = pf[0], f1 = pf[1], f2 = pf[2], f3 = pf[3];
-        for (int k0 = 0; k0 < K4; k0 += 32 * KB) {
+        for (int k0 = 0; k0 < K4; k0 += NQ * KB) {
             double2 raw[KB][4];
 #pragma unroll
             for (int b = 0; b < KB; b++) {
-                const int kc = min(k0 + kq + 32 * b, km);
+                const int kc = min(k0 + kq + NQ * b, km);
 #pragma unroll
                 for (int r = 0; r < 4; r++) raw[b][r] = *reinterpret_cast<const double2 *>(a + r * azrow + 2 * kc);
             }
 #pragma unroll
             for (int b = 0; b < KB; b++) {
-                const int k = k0 + kq + 32 * b;
+                const int k = k0 + kq + NQ * b;
                 if (k >= K4 || zz >= DZC) continue;
                 double cr = 0.0, ci = 0.0;
                 if (zin && k <= km) {
@@ -636,8 +652,8 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
 #define DFT_U(MA_, B_)                                                                                                                 \
     do {                                                                                                                               \
         constexpr int np_ = ((MA_) & 1) + (((MA_) >> 1) & 1) + (((MA_) >> 2) & 1) + ((B_) ? 1 : 0);                                    \
-        if constexpr (E8 && np_ <= NPM)                                                                                                \
-            dft_unit8<MA_, B_, ST>(twl, Cset[0][0], Cset[0][1], Cset[1][0], Cset[1][1], phys, V, v, N, p0, nz, z0, zc, L, km, mt, lane, of, dbg_loops);   \
+        if constexpr (E8 && np_ <= NPM && !(HT && (B_)))                                                                               \
+            dft_unit8<MA_, B_, ST, HT>(twl, Cset[0][0], Cset[0][1], Cset[1][0], Cset[1][1], phys, V, v, N, p0, nz, z0, zc, L, km, mt, lane, of, dbg_loops);   \
         else if constexpr (!E8)                                                                                                        \
             dft_unit<MA_, B_, ST>(twl, Cset[0][0], Cset[0][1], Cset[1][0], Cset[1][1], phys, V, v, N, p0, nz, z0, zc, L, km, K4, mt, lane, of);   \
     } while (0)
@@ -1549,6 +1565,24 @@ void launch_rl_inverse_dft(sx_handle *h, const int *d_mask) {
             const size_t lds2 = sizeof(double) * (2 * (size_t)lcap + (size_t)4 * kz * CST) + pad;
             const int two = lds2 <= 160 * 1024 ? 1 : 0;            // two coefficient sets beside the twiddle table: kmax <= ~260
             const size_t ldsm = two ? lds2 : sizeof(double) * (2 * (size_t)lcap + (size_t)2 * kz * CST) + pad;
+            // two 256-thread workgroups per CU (HT) where one set + half the twiddle table fit 80 KB
+            const size_t ldsh = sizeof(double) * ((size_t)2 * kz * CST + (size_t)lcap);
+            if (e8 && h->dft_half_wg && ldsh <= 80 * 1024) {
+#define DFT_INVH(ST)                                                                                                                 \
+                {                                                                                                                    \
+                    auto kern = k_rl_inverse_dft_merged<ST, 2, true>;                                                                \
+                    HIPCHK3(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsh)); \
+                    hipLaunchKernelGGL(kern, g, dim3(256), ldsh, h->stream, az, planes_of<ST>(h->d_phys, h->V, h->N), h->d_phi, h->d_L, \
+                                       h->d_kmax, h->d_pstart, h->d_twoff, h->d_tw, h->d_phoff, h->d_ph, h->V, h->nz, h->nsz, h->K2, \
+                                       h->nrings, h->N, azrow, h->slot[0], h->slot[1], h->slot[2], h->slot[3], h->slot[4], h->slot[5], \
+                                       h->slot[6], d_mask, h->d_dft_items[which] + 2 * nbig, lcap, kz, 0);                           \
+                }
+                if (h->f32) DFT_INVH(float) else DFT_INVH(double)
+#undef DFT_INVH
+                HIPCHK3(hipGetLastError());
+                timer_end(h);
+                return;
+            }
 #define DFT_INVM(ST)                                                                                                                 \
             {                                                                                                                        \
                 auto kern = e8 ? k_rl_inverse_dft_merged<ST, 2> : k_rl_inverse_dft_merged<ST, 0>;                                    \

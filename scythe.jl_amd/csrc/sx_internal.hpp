@@ -158,6 +158,7 @@ struct sx_handle {
     hipGraphExec_t graph_exec[3] = {nullptr, nullptr, nullptr};
     hipStream_t graph_stream = nullptr;      // capture / replay stream when the handle runs on the (uncapturable) null stream
     int fft_reg = 1;                         // 256-point inverse transforms: register-resident passes with lane swaps (SX_FFT_REG=0: every pass through LDS)
+    int dft_half_wg = 1;                     // eighth-wave kernel as two 256-thread workgroups per CU where one set + half a twiddle table fit 80 KB (SX_DFT_HALFWG=0: one 512-thread workgroup)
     int dft_eighth = 2;                      // merged kernel: eighth-wave units of two planes (round 4; SX_DFT_EIGHTH=0: quarter-wave units of up to four)
     int dft_merge = 1;                       // RLZ native rings: merged-pass inverse DFT kernel (SX_DFT_MERGE=0: one set per pass, whole tiles per wave)
     int rl_quarter = 1;                      // RL grids: quarter-wave DFT kernels over one work list (SX_DFT_RLQ=0: the half-ring kernels in two ring classes)

@@ -103,7 +103,7 @@ FLAGS = {"SX_OVERLAP": ["0", "1", "2"], "SX_DEFER_DIAG": ["0", "1"], "SX_FUSE_ZI
 # round-4 kernels and the kernels they replace (per-handle switches read at sx_create): parallel-cyclic-reduction / serial spline solve,
 # fused matrix-core / general RZ transforms, matrix-core / scalar semi-implicit adjustment, register / LDS passes of the inverse FFT,
 # merged-pass / one-set-per-pass native inverse DFT, quarter-wave / half-ring RL DFT kernels, hipGraph replay / plain launches
-FLAGS_R4 = {"SX_SOLVE_PCR": ["0", "1"], "SX_RZ_FUSED": ["0", "1"], "SX_SEMI_MFMA": ["0", "1"], "SX_FFT_REG": ["0", "1"], "SX_DFT_MERGE": ["0", "1"], "SX_DFT_EIGHTH": ["0", "2"],
+FLAGS_R4 = {"SX_SOLVE_PCR": ["0", "1"], "SX_RZ_FUSED": ["0", "1"], "SX_SEMI_MFMA": ["0", "1"], "SX_FFT_REG": ["0", "1"], "SX_DFT_MERGE": ["0", "1"], "SX_DFT_EIGHTH": ["0", "2"], "SX_DFT_HALFWG": ["0", "1"],
             "SX_DFT_RLQ": ["0", "1"], "SX_GRAPH": ["0", "1"]}
 
 

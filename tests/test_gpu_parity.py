@@ -466,18 +466,23 @@ def test_merged_pass_native_inverse_dft_equals_the_one_set_per_pass_kernel(monke
         assert np.abs(f1[:, v] - f0[:, v]).max() <= 1e-11 * max(np.abs(f0[:, v]).max(), 1e-300), v
 
 
-@pytest.mark.parametrize("planes", ["2", "0"])
+@pytest.mark.parametrize("planes", ["2", "2 whole workgroup", "0"])
 @pytest.mark.parametrize("num_cells,zDim", [(3, 8), (4, 8), (6, 10), (23, 16), (44, 20), (67, 16), (86, 8), (100, 8)])
 def test_eighth_wave_native_inverse_dft_equals_the_one_set_per_pass_kernel(monkeypatch, num_cells, zDim, planes):
     """The eighth-wave units of the merged kernel (the default: even wavenumbers folded once more about the middle of the quarter
     ring, rows l and L/4 - l in one unit of two planes) and its quarter-wave units (SX_DFT_EIGHTH=0) against the one-set-per-pass
     quarter-wave kernel: every slot of tileTransform! on random coefficients and 3 steps of the boundary-layer set.  Ring lengths
     4 .. 404: L/4 odd and even (with and without a self-mirrored row), one to four eighth-ring row tiles, the last round split by
-    planes."""
+    planes.  The eighth-wave kernel runs as two 256-thread workgroups per CU with one coefficient set and half a twiddle table each where
+    those fit 80 KB of LDS (up to 85 cells; the default) and as one 512-thread workgroup with two sets ("whole workgroup": SX_DFT_HALFWG=0,
+    and every patch beyond 85 cells)."""
     import scythe_jl_amd as S
     case = cases.rlz_hrbl(num_cells=num_cells, zDim=zDim)
     case["ts"] = 0.2
     gp, mp = cases.hip_params(case)
+    if "whole" in planes:
+        monkeypatch.setenv("SX_DFT_HALFWG", "0")
+    planes = planes.split()[0]
     monkeypatch.setenv("SX_DFT_EIGHTH", str(planes))
     g1 = S.Grid(gp, mp)
     monkeypatch.delenv("SX_DFT_EIGHTH")
