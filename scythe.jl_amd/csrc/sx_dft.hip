@@ -361,7 +361,7 @@ __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const
     const int i = lane & 15, kk = lane >> 4;
     const int Lh = L / 2, M = L / 4, Mh = M / 2;
     [[maybe_unused]] const long long dbg_l0 = DFT_NOW();
-    const int lrow = min(mt * 16 + i, Mh), lmir = M - lrow;
+    const int lrow = min(mt * 16 + i, Mh);
     constexpr int NP = ((MA & 1) ? 1 : 0) + ((MA & 2) ? 1 : 0) + ((MA & 4) ? 1 : 0) + (HASB ? 1 : 0);
     constexpr int I1 = 0, I2 = (MA & 1) ? 1 : 0, I4 = I2 + ((MA & 2) ? 1 : 0), IB = I4 + ((MA & 4) ? 1 : 0);
     dft_d4 Ec[NP][2], Es[NP][2], Oc[NP][2], Os[NP][2];       // E*[plane][class 0 / 2], O*[plane][rows l / rows M - l]
@@ -378,50 +378,62 @@ __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const
     // them in memory (profiles/r04/eighth_wave_alignment.txt); this form is 0.905-0.912 ms at eight different offsets.  An odd step
     // count runs one step on zero rows (the staged rows end at a multiple of 32); the last request goes one step beyond them (inside
     // the LDS allocation: the launcher adds 32 rows; the values are not used).
-    auto tw_at = [&](int m) __attribute__((always_inline)) {
-        if constexpr (!HT) return twl[m];
+    // Twiddle fetch: index (k l) mod L advanced by add, subtract, unsigned minimum.  HT: the table holds -tw[m] for m < L / 2; with
+    // u = m - L/2 the entry is min(m, u) (unsigned) and the value's sign the sign bit of u - an XOR mask applied to the pair once it
+    // has arrived (in the matrix-core block, not at the request).  Every vector instruction here is time the matrix pipe stands still
+    // (an MFMA holds its SIMD's vector issue port), see DESIGN.md 7.
+    auto flip = [](double x, int mask) __attribute__((always_inline)) { return __hiloint2double(__double2hiint(x) ^ mask, __double2loint(x)); };
+    auto advance = [&](int &m, int step) __attribute__((always_inline)) {
+        const unsigned t = (unsigned)(m + step);
+        m = (int)min(t, t - (unsigned)L);
+    };
+    auto tw_req = [&](int m, int &mask) __attribute__((always_inline)) {
+        if constexpr (!HT) { mask = 0; return twl[m]; }
         else {
-            const bool ng = m >= Lh;
-            double2 t = twl[ng ? m - Lh : m];
-            if (ng) { t.x = -t.x; t.y = -t.y; }
-            return t;
+            const int u = m - Lh;
+            mask = u & (int)0x80000000;
+            return twl[min((unsigned)m, (unsigned)u)];
         }
     };
-    struct OddOps { double2 t, tm; double ac, as, bc, bs; };
-    struct EvenOps { double2 t0, t2; double ac0, as0, ac2, as2, bc0, bs0, bc2, bs2; };
+    struct OddOps { double2 t; int sm; double ac, as, bc, bs; };
+    struct EvenOps { double2 t0, t2; int sm0, sm2; double ac0, as0, ac2, as2, bc0, bs0, bc2, bs2; };
     if (km >= 1) {                                            // odd wavenumbers k = 8 js + 2 kk + 1, rows l and M - l
+        // The mirrored rows need no fetch of their own: k theta (M - l) = k pi / 2 - k theta l, so for odd k
+        // (cos, sin)(k theta (M - l)) = s (sin, cos)(k theta l) with s = +1 for k = 1 mod 4 (kk even), -1 for k = 3 mod 4 (kk odd).
         const int nst = ((km - 1) / 2 + 1 + 3) / 4;
-        int m = ((2 * kk + 1) * lrow) % L, mm = ((2 * kk + 1) * lmir) % L;
-        const int s8 = (8 * lrow) % L, sm8 = (8 * lmir) % L;
+        int m = ((2 * kk + 1) * lrow) % L;
+        const int s8 = (8 * lrow) % L;
+        const int sgm = (kk & 1) ? (int)0x80000000 : 0;
         double kd = (double)(2 * kk + 1);
         int ko = (2 * kk + 1) * CST + i;                       // rows km + 1 .. Kz - 1 of the coefficient tiles hold zeros
         auto load = [&](OddOps &x) __attribute__((always_inline)) {
-            x.t = tw_at(m); x.tm = tw_at(mm);
+            x.t = tw_req(m, x.sm);
             if (MA != 0) { x.ac = CcA[ko]; x.as = CsA[ko]; }
             if (HASB) { x.bc = CcB[ko]; x.bs = CsB[ko]; }
-            m += s8; if (m >= L) m -= L;
-            mm += sm8; if (mm >= L) mm -= L;
+            advance(m, s8);
             ko += 8 * CST;
         };
         auto hold = [&](OddOps &x) __attribute__((always_inline)) {      // the values exist from here on (an opaque use: the loads cannot move past it)
-            asm volatile("" : "+v"(x.t.x), "+v"(x.t.y), "+v"(x.tm.x), "+v"(x.tm.y));
+            asm volatile("" : "+v"(x.t.x), "+v"(x.t.y));
             if (MA != 0) asm volatile("" : "+v"(x.ac), "+v"(x.as));
             if (HASB) asm volatile("" : "+v"(x.bc), "+v"(x.bs));
         };
         auto mma = [&](const OddOps &x) __attribute__((always_inline)) {
+            const double tx = HT ? flip(x.t.x, x.sm) : x.t.x, ty = HT ? flip(x.t.y, x.sm) : x.t.y;
+            const double tmx = flip(x.t.y, x.sm ^ sgm), tmy = flip(x.t.x, x.sm ^ sgm);      // rows M - l
             if (MA & 1) {
-                DFT8_MM(Oc[I1][0], x.t.x, x.ac); DFT8_MM(Os[I1][0], x.t.y, x.as); DFT8_MM(Oc[I1][1], x.tm.x, x.ac); DFT8_MM(Os[I1][1], x.tm.y, x.as);
+                DFT8_MM(Oc[I1][0], tx, x.ac); DFT8_MM(Os[I1][0], ty, x.as); DFT8_MM(Oc[I1][1], tmx, x.ac); DFT8_MM(Os[I1][1], tmy, x.as);
             }
             if (MA & 2) {                                      // i k (cr + i ci): cosine part -k ci, sine part k cr
                 const double b1 = -kd * x.as, b2 = kd * x.ac;
-                DFT8_MM(Oc[I2][0], x.t.x, b1); DFT8_MM(Os[I2][0], x.t.y, b2); DFT8_MM(Oc[I2][1], x.tm.x, b1); DFT8_MM(Os[I2][1], x.tm.y, b2);
+                DFT8_MM(Oc[I2][0], tx, b1); DFT8_MM(Os[I2][0], ty, b2); DFT8_MM(Oc[I2][1], tmx, b1); DFT8_MM(Os[I2][1], tmy, b2);
             }
             if (MA & 4) {
                 const double k2 = -(kd * kd), b1 = k2 * x.ac, b2 = k2 * x.as;
-                DFT8_MM(Oc[I4][0], x.t.x, b1); DFT8_MM(Os[I4][0], x.t.y, b2); DFT8_MM(Oc[I4][1], x.tm.x, b1); DFT8_MM(Os[I4][1], x.tm.y, b2);
+                DFT8_MM(Oc[I4][0], tx, b1); DFT8_MM(Os[I4][0], ty, b2); DFT8_MM(Oc[I4][1], tmx, b1); DFT8_MM(Os[I4][1], tmy, b2);
             }
             if (HASB) {
-                DFT8_MM(Oc[IB][0], x.t.x, x.bc); DFT8_MM(Os[IB][0], x.t.y, x.bs); DFT8_MM(Oc[IB][1], x.tm.x, x.bc); DFT8_MM(Os[IB][1], x.tm.y, x.bs);
+                DFT8_MM(Oc[IB][0], tx, x.bc); DFT8_MM(Os[IB][0], ty, x.bs); DFT8_MM(Oc[IB][1], tmx, x.bc); DFT8_MM(Os[IB][1], tmy, x.bs);
             }
             kd += 8.0;
         };
@@ -448,11 +460,11 @@ __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const
         double kd0 = (double)(4 * kk), kd2 = kd0 + 2.0;
         int ko = 4 * kk * CST + i;
         auto load = [&](EvenOps &x) __attribute__((always_inline)) {
-            x.t0 = tw_at(m0); x.t2 = tw_at(m2);
+            x.t0 = tw_req(m0, x.sm0); x.t2 = tw_req(m2, x.sm2);
             if (MA != 0) { x.ac0 = CcA[ko]; x.as0 = CsA[ko]; x.ac2 = CcA[ko + 2 * CST]; x.as2 = CsA[ko + 2 * CST]; }
             if (HASB) { x.bc0 = CcB[ko]; x.bs0 = CsB[ko]; x.bc2 = CcB[ko + 2 * CST]; x.bs2 = CsB[ko + 2 * CST]; }
-            m0 += s16; if (m0 >= L) m0 -= L;
-            m2 += s16; if (m2 >= L) m2 -= L;
+            advance(m0, s16);
+            advance(m2, s16);
             ko += 16 * CST;
         };
         auto hold = [&](EvenOps &x) __attribute__((always_inline)) {
@@ -461,20 +473,22 @@ __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const
             if (HASB) asm volatile("" : "+v"(x.bc0), "+v"(x.bs0), "+v"(x.bc2), "+v"(x.bs2));
         };
         auto mma = [&](const EvenOps &x) __attribute__((always_inline)) {
+            const double t0x = HT ? flip(x.t0.x, x.sm0) : x.t0.x, t0y = HT ? flip(x.t0.y, x.sm0) : x.t0.y;
+            const double t2x = HT ? flip(x.t2.x, x.sm2) : x.t2.x, t2y = HT ? flip(x.t2.y, x.sm2) : x.t2.y;
             if (MA & 1) {
-                DFT8_MM(Ec[I1][0], x.t0.x, x.ac0); DFT8_MM(Es[I1][0], x.t0.y, x.as0); DFT8_MM(Ec[I1][1], x.t2.x, x.ac2); DFT8_MM(Es[I1][1], x.t2.y, x.as2);
+                DFT8_MM(Ec[I1][0], t0x, x.ac0); DFT8_MM(Es[I1][0], t0y, x.as0); DFT8_MM(Ec[I1][1], t2x, x.ac2); DFT8_MM(Es[I1][1], t2y, x.as2);
             }
             if (MA & 2) {
-                DFT8_MM(Ec[I2][0], x.t0.x, -kd0 * x.as0); DFT8_MM(Es[I2][0], x.t0.y, kd0 * x.ac0);
-                DFT8_MM(Ec[I2][1], x.t2.x, -kd2 * x.as2); DFT8_MM(Es[I2][1], x.t2.y, kd2 * x.ac2);
+                DFT8_MM(Ec[I2][0], t0x, -kd0 * x.as0); DFT8_MM(Es[I2][0], t0y, kd0 * x.ac0);
+                DFT8_MM(Ec[I2][1], t2x, -kd2 * x.as2); DFT8_MM(Es[I2][1], t2y, kd2 * x.ac2);
             }
             if (MA & 4) {
                 const double q0 = -(kd0 * kd0), q2 = -(kd2 * kd2);
-                DFT8_MM(Ec[I4][0], x.t0.x, q0 * x.ac0); DFT8_MM(Es[I4][0], x.t0.y, q0 * x.as0);
-                DFT8_MM(Ec[I4][1], x.t2.x, q2 * x.ac2); DFT8_MM(Es[I4][1], x.t2.y, q2 * x.as2);
+                DFT8_MM(Ec[I4][0], t0x, q0 * x.ac0); DFT8_MM(Es[I4][0], t0y, q0 * x.as0);
+                DFT8_MM(Ec[I4][1], t2x, q2 * x.ac2); DFT8_MM(Es[I4][1], t2y, q2 * x.as2);
             }
             if (HASB) {
-                DFT8_MM(Ec[IB][0], x.t0.x, x.bc0); DFT8_MM(Es[IB][0], x.t0.y, x.bs0); DFT8_MM(Ec[IB][1], x.t2.x, x.bc2); DFT8_MM(Es[IB][1], x.t2.y, x.bs2);
+                DFT8_MM(Ec[IB][0], t0x, x.bc0); DFT8_MM(Es[IB][0], t0y, x.bs0); DFT8_MM(Ec[IB][1], t2x, x.bc2); DFT8_MM(Es[IB][1], t2y, x.bs2);
             }
             kd0 += 16.0; kd2 += 16.0;
         };
@@ -568,7 +582,11 @@ k_rl_inverse_dft_merged(const double *__restrict__ Az, Planes<ST> phys, const do
     const double2 *phr = ph + phoff[ring];
     const int64_t p0 = pstart[ring];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
-    for (int m = tid; m < (HT ? L / 2 : L); m += blockDim.x) twl[m] = tw[twoff[ring] + m];
+    for (int m = tid; m < (HT ? L / 2 : L); m += blockDim.x) {
+        double2 t = tw[twoff[ring] + m];
+        if (HT) { t.x = -t.x; t.y = -t.y; }                     // the half table holds -tw[m] (the fetch's sign mask is then one AND, see dft_unit8)
+        twl[m] = t;
+    }
 
     // stored sets q: (sz, d) = (0,0) value [planes u, d/dlambda, d2/dlambda2], (0,1) d/dr, (0,2) d2/dr2, (1,0) d/dz, (2,0) d2/dz2.
     // Everything about the passes lives in scalars (bit fields), not in indexed private arrays (those would sit in scratch memory).
