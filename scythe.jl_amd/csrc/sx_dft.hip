@@ -514,37 +514,44 @@ __device__ __forceinline__ void dft_unit8(const double2 *__restrict__ twl, const
 #endif
     dbg_loops += DFT_NOW() - dbg_l0;
     if (i >= zc) return;
-    auto put = [&](int slot, int64_t pt, double val) {
-        if (slot == 0) phys.val[(int64_t)v * N + pt] = val;
-        else phys.der[((int64_t)(slot - 1) * V + v) * N + pt] = (ST)val;
-    };
-    auto put4 = [&](int slot, int lo, double Pe, double Po, double Qe, double Qo) {
-        const double Ps = Pe + Po, Pd = Pe - Po, Qs = Qe + Qo, Qd = Qe - Qo;
-        put(slot, (p0 + lo) * nz + z0 + i, Ps - Qs);
-        if (lo > 0) put(slot, (p0 + (L - lo)) * nz + z0 + i, Ps + Qs);
-        if (lo < M) {
-            put(slot, (p0 + (Lh - lo)) * nz + z0 + i, Pd + Qd);
-            if (lo > 0) put(slot, (p0 + (Lh + lo)) * nz + z0 + i, Pd - Qd);
-        }
-    };
     int slots[NP];
     if (MA & 1) slots[I1] = o.slot[0];
     if (MA & 2) slots[I2] = o.slot[1];
     if (MA & 4) slots[I4] = o.slot[2];
     if (HASB) slots[IB] = o.slot[3];
-    // (the caller runs the plane chunks of a tile in a loop: an opaque copy of the tile index keeps the compiler from hoisting the 32
-    // point offsets of the stores out of that loop - it spilled them, and a spill reload waits for every store in flight.  An
-    // unguarded form of these stores for tiles without an end row, 32-bit offsets from per-plane bases, was measured: 0.915 vs 0.907 ms.)
+    // Stores through a per-plane base pointer (this lane's level of the ring's point 0) and 32-bit point offsets: the 64-bit
+    // multiply-add per stored value of the first version was vector-ALU time the matrix pipe stood still for.  (The caller runs the
+    // plane chunks of a tile in a loop: an opaque copy of the tile index keeps the compiler from hoisting the offsets out of that
+    // loop - it spilled them, and a spill reload waits for every store in flight.)
     int mto = mt;
     asm volatile("" : "+v"(mto));
+    const int64_t ib = p0 * nz + z0 + i;
+    const int nzL = L * nz, nzH = Lh * nz, nzM = M * nz;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int lo = mto * 16 + kk + 4 * r;
-        if (lo > Mh) continue;
+    for (int p = 0; p < NP; p++) {
+        const int slot = slots[p];
+        double *bv = phys.val + (int64_t)v * N + ib;
+        ST *bd = phys.der + ((int64_t)(slot > 0 ? slot - 1 : 0) * V + v) * N + ib;
+        auto put = [&](int off, double val) __attribute__((always_inline)) {
+            if (slot == 0) bv[off] = val;
+            else bd[off] = (ST)val;
+        };
+        auto put4 = [&](int lo, int off, double Pe, double Po, double Qe, double Qo) __attribute__((always_inline)) {
+            const double Ps = Pe + Po, Pd = Pe - Po, Qs = Qe + Qo, Qd = Qe - Qo;
+            put(off, Ps - Qs);
+            if (lo > 0) put(nzL - off, Ps + Qs);
+            if (lo < M) {
+                put(nzH - off, Pd + Qd);
+                if (lo > 0) put(nzH + off, Pd - Qd);
+            }
+        };
 #pragma unroll
-        for (int p = 0; p < NP; p++) {
-            put4(slots[p], lo, Ec[p][0][r] + Ec[p][1][r], Oc[p][0][r], Es[p][0][r] + Es[p][1][r], Os[p][0][r]);
-            if (M - lo != lo) put4(slots[p], M - lo, Ec[p][0][r] - Ec[p][1][r], Oc[p][1][r], Es[p][1][r] - Es[p][0][r], Os[p][1][r]);
+        for (int r = 0; r < 4; r++) {
+            const int lo = mto * 16 + kk + 4 * r;
+            if (lo > Mh) continue;
+            const int off = lo * nz;
+            put4(lo, off, Ec[p][0][r] + Ec[p][1][r], Oc[p][0][r], Es[p][0][r] + Es[p][1][r], Os[p][0][r]);
+            if (M - lo != lo) put4(M - lo, nzM - off, Ec[p][0][r] - Ec[p][1][r], Oc[p][1][r], Es[p][1][r] - Es[p][0][r], Os[p][1][r]);
         }
     }
 }
