@@ -48,6 +48,13 @@ constexpr int DFT_LMAX = 5120;   // longest ring the LDS-resident twiddle table 
 constexpr int DZC = 16;       // levels per workgroup = MFMA N
 constexpr int CST = 17;       // row stride (doubles) of the LDS tiles: 4 consecutive rows land in different banks
 
+// (m + step) mod L for 0 <= m, step < L as add, subtract, unsigned minimum (the wrapped candidate is huge when no wrap is due): one
+// instruction fewer than compare-and-subtract in loops whose vector instructions are matrix-pipe time
+__device__ __forceinline__ int wrap_add(int m, int step, int L) {
+    const unsigned t = (unsigned)(m + step);
+    return (int)min(t, t - (unsigned)L);
+}
+
 // ------------------------------------------------------------------------------------------------ inverse
 // One row-tile pair of the half ring: rows l0 / l1 (clamped), angle index m = (k l) mod L advancing by 4 l per K step.
 struct RowPair {
@@ -57,8 +64,8 @@ struct RowPair {
         s0 = (int)(((int64_t)4 * l0) % L); s1 = (int)(((int64_t)4 * l1) % L);
     }
     __device__ __forceinline__ void step(int L) {
-        m0 += s0; if (m0 >= L) m0 -= L;
-        m1 += s1; if (m1 >= L) m1 -= L;
+        m0 = wrap_add(m0, s0, L);
+        m1 = wrap_add(m1, s1, L);
     }
 };
 
@@ -205,8 +212,7 @@ k_rl_inverse_dft(const double *__restrict__ Az, Planes<ST> phys, const double *_
                         qll[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, k2 * bs, qll[par], 0, 0, 0);
                     }
                     kd += 8.0;
-                    m += sm8;
-                    if (m >= L) m -= L;
+                    m = wrap_add(m, sm8, L);
                 }
             }
             // D tile: lane holds column n = lane & 15 (level), rows (lane >> 4) + 4 r (points l of the quarter ring)
@@ -312,8 +318,7 @@ __device__ __forceinline__ void dft_unit(const double2 *__restrict__ twl, const 
                 Q[IB][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, Q[IB][par], 0, 0, 0);
             }
             kd += 8.0;
-            m += sm8;
-            if (m >= L) m -= L;
+            m = wrap_add(m, sm8, L);
         }
     }
     if (i >= zc) return;
@@ -841,8 +846,7 @@ k_rl_inverse_dft_big(const double *__restrict__ Az, Planes<ST> phys, const doubl
                         qll[par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, k2 * bs, qll[par], 0, 0, 0);
                     }
                     kd += 8.0;
-                    m += sm8;
-                    if (m >= L) m -= L;
+                    m = wrap_add(m, sm8, L);
                 }
             }
         }
@@ -1046,8 +1050,7 @@ k_fl_forward_dft(const double *__restrict__ np1, double *__restrict__ Fl, const 
                 const double2 t = twl[m];
                 ac[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(ls + kk) * CST + n], t.x, ac[q], 0, 0, 0);
                 as[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xd[(ls + kk) * CST + n], t.y, as[q], 0, 0, 0);
-                m += fourk;
-                if (m >= L) m -= L;
+                m = wrap_add(m, fourk, L);
             }
         }
     }
@@ -1297,8 +1300,7 @@ k_rl_inverse_dft_planes_q(const double *__restrict__ A, Planes<ST> phys, const d
                     P[g][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.x, bc, P[g][par], 0, 0, 0);
                     Q[g][par] = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.y, bs, Q[g][par], 0, 0, 0);
                 }
-                m += sm8;
-                if (m >= L) m -= L;
+                m = wrap_add(m, sm8, L);
             }
         }
     }
@@ -1386,8 +1388,7 @@ k_fl_forward_dft_qp(const double *__restrict__ np1, double *__restrict__ Fl, con
             const double2 t = twl[m];
             ac = __builtin_amdgcn_mfma_f64_16x16x4f64(xc, t.x, ac, 0, 0, 0);
             as = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, t.y, as, 0, 0, 0);
-            m += fourk;
-            if (m >= L) m -= L;
+            m = wrap_add(m, fourk, L);
         }
     }
     const int k = 2 * (16 * tq + n) + par;
